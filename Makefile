@@ -1,0 +1,35 @@
+# Build the C-ABI libraries.
+#   make hip   -> star_amd/libstar_hip.so       (gfx950, the product)
+#   make emu   -> tools/hostemu/libstar_emu.so   (SIMT emulator build, tests only)
+#   make oracle-> oracle C helpers (none yet)
+CSRC := star_amd/csrc
+SRCS := $(wildcard $(CSRC)/*.cpp)
+HIPCC ?= hipcc
+CLANGXX ?= /opt/rocm/lib/llvm/bin/clang++
+HIP_OBJS := $(patsubst $(CSRC)/%.cpp,build/hip/%.o,$(SRCS))
+EMU_OBJS := $(patsubst $(CSRC)/%.cpp,build/emu/%.o,$(SRCS)) build/emu/hostemu.o
+HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -x hip -Wno-unused-value -ffp-contract=fast
+EMUFLAGS := -O2 -g -std=c++17 -fPIC -DSTAR_HOSTEMU=1 -mavx2 -mf16c -mfma -Wno-unused-value -Wno-psabi -Wno-psabi
+
+all: hip emu
+hip: star_amd/libstar_hip.so
+emu: tools/hostemu/libstar_emu.so
+
+build/hip/%.o: $(CSRC)/%.cpp $(wildcard $(CSRC)/*.h) include/star_hip.h
+	@mkdir -p build/hip
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+star_amd/libstar_hip.so: $(HIP_OBJS)
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC $^ -o $@
+
+build/emu/%.o: $(CSRC)/%.cpp $(wildcard $(CSRC)/*.h) include/star_hip.h
+	@mkdir -p build/emu
+	$(CLANGXX) $(EMUFLAGS) -c $< -o $@
+build/emu/hostemu.o: tools/hostemu/hostemu.cpp $(CSRC)/hostemu.h
+	@mkdir -p build/emu
+	$(CLANGXX) $(EMUFLAGS) -c $< -o $@
+tools/hostemu/libstar_emu.so: $(EMU_OBJS)
+	$(CLANGXX) -shared -fPIC $^ -o $@ -lm
+
+clean:
+	rm -rf build star_amd/libstar_hip.so tools/hostemu/libstar_emu.so
+.PHONY: all hip emu clean

@@ -1,0 +1,116 @@
+// ctx.h -- per-device context behind the C ABI (include/star_hip.h).
+#pragma once
+#include "rt.h"
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+#include <memory>
+
+namespace star {
+
+enum DType : int { DT_F16 = 0, DT_BF16 = 1, DT_F32 = 2 };
+
+// size-bucketed caching allocator: every kernel runs on ctx->stream, so a freed
+// block may be handed out again immediately (stream order protects it).
+class Pool {
+ public:
+  ~Pool() { release(); }
+  void* alloc(size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (bytes == 0) bytes = 256;
+    auto it = free_.lower_bound(bytes);
+    if (it != free_.end() && it->first <= bytes + (bytes >> 2)) {
+      void* p = it->second;
+      free_.erase(it);
+      live_[p] = bytes_of_[p];
+      in_use_ += bytes_of_[p];
+      if (in_use_ > peak_) peak_ = in_use_;
+      return p;
+    }
+    void* p = nullptr;
+    if (rt::dev_malloc(&p, bytes)) {
+      // try again after dropping the cache
+      trim();
+      if (rt::dev_malloc(&p, bytes)) return nullptr;
+    }
+    bytes_of_[p] = bytes;
+    live_[p] = bytes;
+    total_ += bytes;
+    in_use_ += bytes;
+    if (in_use_ > peak_) peak_ = in_use_;
+    return p;
+  }
+  void free(void* p) {
+    if (!p) return;
+    auto it = live_.find(p);
+    if (it == live_.end()) return;
+    in_use_ -= it->second;
+    free_.emplace(it->second, p);
+    live_.erase(it);
+  }
+  void trim() {
+    for (auto& kv : free_) { rt::dev_free(kv.second); total_ -= kv.first; bytes_of_.erase(kv.second); }
+    free_.clear();
+  }
+  void release() {
+    trim();
+    for (auto& kv : live_) { rt::dev_free(kv.first); }
+    live_.clear();
+    bytes_of_.clear();
+    total_ = in_use_ = 0;
+  }
+  size_t total() const { return total_; }
+  size_t peak() const { return peak_; }
+ private:
+  std::multimap<size_t, void*> free_;
+  std::unordered_map<void*, size_t> live_, bytes_of_;
+  size_t total_ = 0, in_use_ = 0, peak_ = 0;
+};
+
+struct Ctx;
+
+// RAII device buffer from the ctx pool
+struct Buf {
+  Ctx* ctx = nullptr;
+  void* p = nullptr;
+  size_t bytes = 0;
+  Buf() = default;
+  Buf(Ctx* c, size_t n);
+  Buf(const Buf&) = delete;
+  Buf& operator=(const Buf&) = delete;
+  Buf(Buf&& o) noexcept : ctx(o.ctx), p(o.p), bytes(o.bytes) { o.p = nullptr; }
+  Buf& operator=(Buf&& o) noexcept;
+  ~Buf();
+  void reset();
+  template <class U> U* as() const { return reinterpret_cast<U*>(p); }
+};
+
+struct HostTensor {
+  std::vector<float> data;
+  std::vector<int64_t> shape;
+};
+
+struct UNetModel;
+struct VaeModel;
+
+struct Ctx {
+  int device = 0;
+  int dtype = DT_F16;
+  hipStream_t stream = nullptr;
+  std::string err;
+  Pool pool;
+  void* zero_page = nullptr;  // 256 B of zeros (conv padding source)
+  std::unordered_map<std::string, HostTensor> host_tensors;  // staged by star_load_tensor
+  std::shared_ptr<UNetModel> unet;   // shared_ptr: deleter bound where the type is complete
+  std::shared_ptr<VaeModel> vae;
+  int fail(const std::string& m) { err = m; return 1; }
+  size_t esize() const { return dtype == DT_F32 ? 4 : 2; }
+};
+
+inline Buf::Buf(Ctx* c, size_t n) : ctx(c), bytes(n) { p = c->pool.alloc(n); }
+inline Buf::~Buf() { reset(); }
+inline void Buf::reset() { if (p && ctx) ctx->pool.free(p); p = nullptr; }
+inline Buf& Buf::operator=(Buf&& o) noexcept { if (this != &o) { reset(); ctx = o.ctx; p = o.p; bytes = o.bytes; o.p = nullptr; } return *this; }
+
+}  // namespace star

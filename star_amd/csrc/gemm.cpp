@@ -1,0 +1,57 @@
+// gemm.cpp -- tile selection + launch for gemm_kernel (see gemm.h).
+#include "ops.h"
+
+namespace star {
+
+template <class T, int BM, int BN, int WM, int WN>
+static int launch_gemm_t(Ctx* ctx, const GemmArgs& a) {
+  GemmParams p{};
+  p.A = a.A; p.W = a.W; p.C = a.C; p.bias = a.bias; p.res = a.res; p.zero_page = ctx->zero_page;
+  p.M = a.M; p.N = a.N; p.K = a.K; p.lda = a.lda; p.ldc = a.ldc; p.ldr = a.ldr;
+  p.H = a.H; p.Wd = a.Wd; p.Cin = a.Cin; p.Ho = a.Ho; p.Wo = a.Wo; p.stride = a.stride; p.pad_t = a.pad_t; p.pad_l = a.pad_l;
+  p.HW = a.HW; p.F = a.F; p.epi = a.epi;
+  p.tiles_m = (a.M + BM - 1) / BM;
+  p.tiles_n = (a.N + BN - 1) / BN;
+  const size_t smem = 2 * (size_t)(BM + BN) * 128;
+  dim3 grid((unsigned)(p.tiles_m * p.tiles_n)), block(WM * WN * 64);
+  switch (a.mode) {
+    case A_PLAIN: STAR_LAUNCH((gemm_kernel<T, BM, BN, WM, WN, A_PLAIN>), grid, block, smem, ctx->stream, p); break;
+    case A_CONV3X3: STAR_LAUNCH((gemm_kernel<T, BM, BN, WM, WN, A_CONV3X3>), grid, block, smem, ctx->stream, p); break;
+    case A_CONV3X3_UP: STAR_LAUNCH((gemm_kernel<T, BM, BN, WM, WN, A_CONV3X3_UP>), grid, block, smem, ctx->stream, p); break;
+    case A_TCONV3: STAR_LAUNCH((gemm_kernel<T, BM, BN, WM, WN, A_TCONV3>), grid, block, smem, ctx->stream, p); break;
+    default: return ctx->fail("gemm: bad A mode");
+  }
+  return 0;
+}
+
+template <class T>
+static int launch_gemm(Ctx* ctx, const GemmArgs& a) {
+  int tile = a.force_tile;
+  if (!tile) {
+    const bool geglu = (a.epi & EPI_GEGLU) != 0;
+    if (a.M <= 4096 && a.N <= 1024) tile = 3;                          // small problems: more, smaller tiles
+    else if (!geglu && a.N % 320 == 0 && a.N % 256 != 0) tile = 2;      // 320 / 640 / 960 / 1920-wide layers
+    else if (a.N <= 128) tile = 4;
+    else tile = 1;
+  }
+  switch (tile) {
+    case 1: return launch_gemm_t<T, 256, 256, 4, 2>(ctx, a);
+    case 2: return launch_gemm_t<T, 256, 320, 4, 2>(ctx, a);
+    case 3: return launch_gemm_t<T, 128, 128, 2, 2>(ctx, a);
+    case 4: return launch_gemm_t<T, 256, 128, 4, 1>(ctx, a);
+  }
+  return ctx->fail("gemm: bad tile id");
+}
+
+int op_gemm(Ctx* ctx, const GemmArgs& a) {
+  if (a.K % 64 != 0) return ctx->fail("gemm: K must be a multiple of 64");
+  if (a.lda % 8 != 0) return ctx->fail("gemm: lda must be a multiple of 8");
+  if (a.mode != A_PLAIN && a.Cin % 64 != 0) return ctx->fail("gemm: conv Cin must be a multiple of 64");
+  if ((a.epi & EPI_GEGLU) && (a.N % 64 != 0)) return ctx->fail("gemm: GEGLU needs N % 64 == 0");
+  if (a.M <= 0 || a.N <= 0) return 0;
+  if (ctx->dtype == DT_F16) return launch_gemm<f16>(ctx, a);
+  if (ctx->dtype == DT_BF16) return launch_gemm<bf16>(ctx, a);
+  return ctx->fail("gemm: unsupported dtype");
+}
+
+}  // namespace star

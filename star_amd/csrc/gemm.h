@@ -1,0 +1,301 @@
+// gemm.h -- the MFMA GEMM core behind every Linear / Conv2d / Conv3d(3,1,1) of the
+// hot path (reference call sites unet_v2v.py:151-155,274,294,
+// 500,526,612,639,648,717,1005,1025,1209-1220).
+//
+//   C[M,N] = epilogue( A'[M,K] * W[N,K]^T )
+//
+// * A' is never materialised for convolutions: the A-tile loader gathers the
+//   NHWC (channels-last, tokens x C) activation rows for each (tap, channel
+//   block) straight into LDS with 16-byte LDS-DMA (global_load_lds), pointing
+//   out-of-image taps at a zero page.  K is ordered (tap, cin); weights are
+//   repacked to [N][taps][Cin] at load time.
+// * Tile BM x BN x 64, 32x32x16 MFMA, two LDS stages, one barrier per K tile.
+//   LDS rows are 128 B (64 k-elements); the 16-B chunk c of row r lives at
+//   chunk position c ^ ((r>>1)&7), applied on the *source* address because
+//   LDS-DMA writes lane-linearly; fragment ds_read_b128 are then conflict-free.
+// * The MFMA is issued "swapped" (rows = n, cols = m) so each lane ends up with
+//   4 consecutive n for one m: the epilogue packs them, stages a 32-row block
+//   through LDS and writes full 16-B row segments (with optional bias, residual
+//   add, GEGLU pairing).
+#pragma once
+#include "prim.h"
+
+namespace star {
+
+enum GemmAMode : int {
+  A_PLAIN = 0,     // A[m][k] = A + m*lda + k
+  A_CONV3X3 = 1,   // 3x3 conv over NHWC, stride s, pad (pad_t, pad_l); K = 9*Cin
+  A_CONV3X3_UP = 2,// nearest 2x upsample + drop first/last row (unet_v2v.py:563-564) fused in front of a 3x3 pad-1 conv
+  A_TCONV3 = 3,    // Conv3d (3,1,1) pad (1,0,0) over frames: K = 3*Cin, source row m + (tap-1)*HW
+};
+
+enum GemmEpi : int {
+  EPI_BIAS = 1,    // + bias[n] (fp32)
+  EPI_RES = 2,     // + res[m][n] (T, row stride ldr)
+  EPI_GEGLU = 4,   // weight rows interleaved in 32-row (value, gate) blocks: out[m][n/2] = (v+bv) * gelu_erf(g+bg)
+  EPI_OUT_F32 = 8, // store fp32 instead of T
+};
+
+struct GemmParams {
+  const void* A;
+  const void* W;      // [N][K] (K contiguous)
+  void* C;
+  const float* bias;  // [N] or null
+  const void* res;    // [M][ldr] or null
+  const void* zero_page;
+  int M, N, K;
+  int lda, ldc, ldr;
+  // conv geometry (A_CONV*): input [NB][H][Wd][lda>=Cin], output rows m = ((nb*Ho)+yo)*Wo+xo
+  int H, Wd, Cin, Ho, Wo, stride, pad_t, pad_l;
+  // temporal geometry (A_TCONV3): m = f*HW + p
+  int HW, F;
+  int epi;
+  int tiles_m, tiles_n;
+};
+
+STAR_DEV float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+template <class T, int BM, int BN, int WM, int WN, int AMODE>
+STAR_GLOBAL void STAR_LAUNCH_BOUNDS(WM * WN * 64)
+gemm_kernel(const GemmParams p) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int BK = 64;
+  constexpr int WTM = BM / WM, WTN = BN / WN;  // wave tile
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int NA = BM * 8 / NT, NW = BN * 8 / NT;  // 16-B chunks per thread per K tile
+  static_assert(BM * 8 % NT == 0 && BN * 8 % NT == 0, "tile/threads mismatch");
+  static_assert(NT % 8 == 0, "");
+  constexpr int A_STAGE = BM * 128, W_STAGE = BN * 128;
+  constexpr int STAGE = A_STAGE + W_STAGE;
+
+  char* smem = dyn_smem();
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+
+  // ---- XCD-aware tile order: blocks that run on one XCD (bid % 8) walk consecutive
+  // logical tile ids, and consecutive ids share the A row panel (different n tile).
+  const int nblk = p.tiles_m * p.tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = bid & 7, slot = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  }
+  const int tile_m = bid / p.tiles_n, tile_n = bid % p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const T* __restrict__ Ag = (const T*)p.A;
+  const T* __restrict__ Wg = (const T*)p.W;
+
+  // ---- per-thread loader state
+  const int pos = tid & 7;
+  // A rows handled by this thread: r_j = (j*NT + tid) >> 3
+  const T* a_ptr[NA];       // PLAIN/TCONV: row base pointer (+ chunk offset)
+  int a_y[NA], a_x[NA], a_f[NA];  // conv / temporal coordinates
+  int a_choff[NA];          // element offset of this thread's (swizzled) chunk within the 64-wide k tile
+#pragma unroll
+  for (int j = 0; j < NA; ++j) {
+    const int r = (j * NT + tid) >> 3;
+    const int c = pos ^ ((r >> 1) & 7);
+    a_choff[j] = c * 8;
+    int m = m0 + r;
+    if (m > p.M - 1) m = p.M - 1;
+    if constexpr (AMODE == A_PLAIN) {
+      a_ptr[j] = Ag + (size_t)m * p.lda + c * 8;
+      a_y[j] = a_x[j] = a_f[j] = 0;
+    } else if constexpr (AMODE == A_TCONV3) {
+      a_ptr[j] = Ag + (size_t)m * p.lda + c * 8;
+      a_f[j] = m / p.HW;
+      a_y[j] = a_x[j] = 0;
+    } else {
+      const int hw = p.Ho * p.Wo;
+      const int nb = m / hw, rem = m - nb * hw;
+      const int yo = rem / p.Wo, xo = rem - yo * p.Wo;
+      a_ptr[j] = Ag + (size_t)nb * p.H * p.Wd * p.lda + c * 8;
+      a_y[j] = yo * p.stride - p.pad_t;
+      a_x[j] = xo * p.stride - p.pad_l;
+      a_f[j] = 0;
+    }
+  }
+  const T* w_ptr[NW];
+#pragma unroll
+  for (int j = 0; j < NW; ++j) {
+    const int r = (j * NT + tid) >> 3;
+    const int c = pos ^ ((r >> 1) & 7);
+    int n = n0 + r;
+    if (n > p.N - 1) n = p.N - 1;
+    w_ptr[j] = Wg + (size_t)n * p.K + c * 8;
+  }
+
+  const int nk = p.K / BK;
+  int tap = 0, c0 = 0;  // (tap, channel offset) of the K tile being staged
+
+  auto stage = [&](int kt, int buf) {
+    char* abuf = smem + buf * STAGE;
+    char* wbuf = abuf + A_STAGE;
+    int ky = 0, kx = 0;
+    if constexpr (AMODE == A_CONV3X3 || AMODE == A_CONV3X3_UP) { ky = tap / 3; kx = tap - ky * 3; }
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const void* src;
+      if constexpr (AMODE == A_PLAIN) {
+        src = a_ptr[j] + kt * BK;
+      } else if constexpr (AMODE == A_TCONV3) {
+        const int f = a_f[j] + tap - 1;
+        src = (f >= 0 && f < p.F) ? (const void*)(a_ptr[j] + (ptrdiff_t)(tap - 1) * p.HW * p.lda + c0) : p.zero_page;
+      } else if constexpr (AMODE == A_CONV3X3) {
+        const int yi = a_y[j] + ky, xi = a_x[j] + kx;
+        src = (yi >= 0 && yi < p.H && xi >= 0 && xi < p.Wd)
+                  ? (const void*)(a_ptr[j] + ((size_t)yi * p.Wd + xi) * p.lda + c0) : p.zero_page;
+      } else {  // A_CONV3X3_UP: conv input U[y][x] = X[(y+1)>>1][x>>1], U is (2H-2) x (2Wd)
+        const int yu = a_y[j] + ky, xu = a_x[j] + kx;
+        src = (yu >= 0 && yu < 2 * p.H - 2 && xu >= 0 && xu < 2 * p.Wd)
+                  ? (const void*)(a_ptr[j] + ((size_t)((yu + 1) >> 1) * p.Wd + (xu >> 1)) * p.lda + c0) : p.zero_page;
+      }
+      // wave-uniform LDS base: chunk q = j*NT + tid -> byte q*16 ; wave base = (j*NT + wave*64)*16
+      glds16(src, abuf + (size_t)(j * NT + wave * 64) * 16);
+    }
+#pragma unroll
+    for (int j = 0; j < NW; ++j) glds16(w_ptr[j] + kt * BK, wbuf + (size_t)(j * NT + wave * 64) * 16);
+    // advance (tap, c0)
+    if constexpr (AMODE != A_PLAIN) {
+      c0 += BK;
+      if (c0 >= p.Cin) { c0 = 0; ++tap; }
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment read offsets (bytes within a stage); row R, chunk c -> R*128 + ((c ^ ((R>>1)&7))<<4)
+  const int frow = lane & 31, fhalf = lane >> 5;
+
+  stage(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    glds_wait();
+    block_sync();
+    if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+    const char* abuf = smem + (kt & 1) * STAGE;
+    const char* wbuf = abuf + A_STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      vec<T, 8> af[TM], wf[TN];
+      const int c = ks * 2 + fhalf;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int R = wm * WTM + i * 32 + frow;
+        af[i] = *reinterpret_cast<const vec<T, 8>*>(abuf + R * 128 + ((c ^ ((R >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int R = wn * WTN + j * 32 + frow;
+        wf[j] = *reinterpret_cast<const vec<T, 8>*>(wbuf + R * 128 + ((c ^ ((R >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = mfma32<T>(wf[j], af[i], acc[i][j]);
+    }
+  }
+
+  // ------------------------------------------------------------------ epilogue
+  // lane holds, for m = i*32 + (lane&31): n = j*32 + 8*(r>>2) + 4*(lane>>5) + (r&3)
+  const bool geglu = (p.epi & EPI_GEGLU) != 0;
+  constexpr int OUT_TN_MAX = TN;
+  const int out_wtn = geglu ? WTN / 2 : WTN;       // output columns per wave
+  const int out_n0 = geglu ? (n0 + wn * WTN) / 2 : (n0 + wn * WTN);
+  const int N_out = geglu ? p.N / 2 : p.N;
+  const int pitch = WTN * 2 + 8;                    // bytes; (pitch/4) % 4 == 2 -> conflict-free b64 writes
+  block_sync();                                     // all MFMA reads of the stages are done
+  char* my = smem + wave * (32 * (WTN * 2 + 8));
+  const bool out_f32 = (p.epi & EPI_OUT_F32) != 0;
+  const float* __restrict__ bias = p.bias;
+
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    // ---- registers -> LDS (T, row-major [32][out_wtn])
+#pragma unroll
+    for (int j = 0; j < OUT_TN_MAX; ++j) {
+      if (geglu && (j & 1)) continue;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int nl = j * 32 + 8 * g + 4 * fhalf;   // local n within wave tile (pre-GEGLU)
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][g * 4 + e];
+        if (p.epi & EPI_BIAS) {
+          const int ng = n0 + wn * WTN + nl;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += bias[(ng + e < p.N) ? ng + e : p.N - 1];
+        }
+        int ncol = nl;
+        if (geglu) {
+          float gt[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) gt[e] = acc[i][(j + 1 < TN) ? j + 1 : j][g * 4 + e];
+          if (p.epi & EPI_BIAS) {
+            const int ng = n0 + wn * WTN + nl + 32;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gt[e] += bias[(ng + e < p.N) ? ng + e : p.N - 1];
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] * gelu_erf(gt[e]);
+          ncol = (j >> 1) * 32 + 8 * g + 4 * fhalf;
+        }
+        vec<T, 4> o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = from_f32<T>(v[e]);
+        *reinterpret_cast<vec<T, 4>*>(my + frow * pitch + ncol * 2) = o;
+      }
+    }
+    block_sync();
+    // ---- LDS -> global, 16-B chunks along rows
+    const int cpr = out_wtn / 8;  // chunks per row
+    const int nchunks = 32 * cpr;
+    for (int q = lane; q < nchunks; q += 64) {
+      const int row = q / cpr, cc = q - row * cpr;
+      const int m = m0 + wm * WTM + i * 32 + row;
+      const int n = out_n0 + cc * 8;
+      if (m >= p.M || n >= N_out) continue;
+      vec<T, 4> lo = *reinterpret_cast<const vec<T, 4>*>(my + row * pitch + cc * 16);
+      vec<T, 4> hi = *reinterpret_cast<const vec<T, 4>*>(my + row * pitch + cc * 16 + 8);
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] = to_f32<T>(lo[e]); v[4 + e] = to_f32<T>(hi[e]); }
+      const bool full = (n + 8 <= N_out);
+      if (p.epi & EPI_RES) {
+        const T* rp = (const T*)p.res + (size_t)m * p.ldr + n;
+        if (full && ((p.ldr & 7) == 0)) {
+          vec<T, 8> rv = *reinterpret_cast<const vec<T, 8>*>(rp);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += to_f32<T>(rv[e]);
+        } else {
+          for (int e = 0; e < 8 && n + e < N_out; ++e) v[e] += to_f32<T>(rp[e]);
+        }
+      }
+      if (out_f32) {
+        float* cp = (float*)p.C + (size_t)m * p.ldc + n;
+        for (int e = 0; e < 8 && n + e < N_out; ++e) cp[e] = v[e];
+      } else {
+        T* cp = (T*)p.C + (size_t)m * p.ldc + n;
+        if (full && ((p.ldc & 7) == 0)) {
+          vec<T, 8> ov;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ov[e] = from_f32<T>(v[e]);
+          *reinterpret_cast<vec<T, 8>*>(cp) = ov;
+        } else {
+          for (int e = 0; e < 8 && n + e < N_out; ++e) cp[e] = from_f32<T>(v[e]);
+        }
+      }
+    }
+    block_sync();
+  }
+}
+
+}  // namespace star

@@ -1,0 +1,292 @@
+// prim.h -- the primitive layer every star_amd kernel is written against.
+//
+// Device build (hipcc, gfx950): thin wrappers over CDNA4 builtins
+//   MFMA 32x32x16 / 16x16x32 (f16, bf16), global_load_lds (16 B LDS-DMA),
+//   ds_read_b64_tr_b16, v_permlane32_swap, wave shuffles.
+// Host-emulator build (-DSTAR_HOSTEMU, tools/hostemu): the same API on the SIMT
+//   emulator, used only to test kernel index logic on machines without a GPU.
+#pragma once
+#include <cstdint>
+#include <cstddef>
+
+#ifdef STAR_HOSTEMU
+#include "hostemu.h"
+#define STAR_DEV inline
+#define STAR_GLOBAL
+#define STAR_LAUNCH_BOUNDS(...)
+#define threadIdx (::star_emu::cur_fiber()->tid)
+#define blockIdx (::star_emu::cur_block()->bid)
+#define blockDim (::star_emu::cur_block()->bdim)
+#define gridDim (::star_emu::cur_block()->gdim)
+using dim3 = ::star_emu::Dim3;
+typedef void* hipStream_t;
+#else
+#include <hip/hip_runtime.h>
+#define STAR_DEV __device__ __forceinline__
+#define STAR_GLOBAL __global__
+#define STAR_LAUNCH_BOUNDS(...) __launch_bounds__(__VA_ARGS__)
+#endif
+
+namespace star {
+
+using f16 = _Float16;
+using bf16 = __bf16;
+
+template <class T, int N>
+using vec = T __attribute__((ext_vector_type(N)));
+using f32x4 = vec<float, 4>;
+using f32x16 = vec<float, 16>;
+using u32x4 = vec<uint32_t, 4>;
+using u32x2 = vec<uint32_t, 2>;
+
+// ---------------------------------------------------------------- conversions
+template <class T>
+STAR_DEV float to_f32(T v);
+template <>
+STAR_DEV float to_f32<f16>(f16 v) { return (float)v; }
+template <>
+STAR_DEV float to_f32<float>(float v) { return v; }
+template <>
+STAR_DEV float to_f32<bf16>(bf16 v) {
+  uint16_t b = __builtin_bit_cast(uint16_t, v);
+  return __builtin_bit_cast(float, (uint32_t)b << 16);
+}
+template <class T>
+STAR_DEV T from_f32(float v);
+template <>
+STAR_DEV f16 from_f32<f16>(float v) { return (f16)v; }
+template <>
+STAR_DEV float from_f32<float>(float v) { return v; }
+template <>
+STAR_DEV bf16 from_f32<bf16>(float v) {  // round-to-nearest-even, NaN preserved
+  uint32_t u = __builtin_bit_cast(uint32_t, v);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return __builtin_bit_cast(bf16, (uint16_t)((u >> 16) | 0x40));
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return __builtin_bit_cast(bf16, (uint16_t)(u >> 16));
+}
+
+STAR_DEV int lane_id() {
+#ifdef STAR_HOSTEMU
+  return ::star_emu::cur_fiber()->lane;
+#else
+  return (int)(threadIdx.x & 63);
+#endif
+}
+
+// ---------------------------------------------------------------- workgroup
+STAR_DEV char* dyn_smem() {
+#ifdef STAR_HOSTEMU
+  return ::star_emu::cur_block()->smem;
+#else
+  extern __shared__ __attribute__((aligned(16))) char star_smem_[];
+  return star_smem_;
+#endif
+}
+STAR_DEV void block_sync() {
+#ifdef STAR_HOSTEMU
+  ::star_emu::block_sync();
+#else
+  __syncthreads();
+#endif
+}
+
+// ---------------------------------------------------------------- MFMA
+// D = A(32x16) * B(16x32) + C.  lane l: a[j] = A[l&31][8*(l>>5)+j], b[j] = B[8*(l>>5)+j][l&31],
+// c[r] = C[(r&3)+8*(r>>2)+4*(l>>5)][l&31]   (verified: profiles/r01_probe_primitives.txt)
+template <class T>
+STAR_DEV f32x16 mfma32(vec<T, 8> a, vec<T, 8> b, f32x16 c) {
+#ifdef STAR_HOSTEMU
+  struct P { float a[8], b[8]; } mine;
+  for (int j = 0; j < 8; ++j) { mine.a[j] = to_f32<T>(a[j]); mine.b[j] = to_f32<T>(b[j]); }
+  auto st = ::star_emu::wave_exchange(&mine, sizeof(mine));
+  const int l = lane_id();
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31;
+    float s = c[r];
+    for (int k = 0; k < 16; ++k) {
+      const P* pa = reinterpret_cast<const P*>(st[row + 32 * (k >> 3)]);
+      const P* pb = reinterpret_cast<const P*>(st[col + 32 * (k >> 3)]);
+      s += pa->a[k & 7] * pb->b[k & 7];
+    }
+    c[r] = s;
+  }
+  return c;
+#else
+  if constexpr (sizeof(T) == 2 && __is_same(T, bf16)) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#endif
+}
+
+// D = A(16x32) * B(32x16) + C. lane l: a[j] = A[l&15][8*(l>>4)+j], b[j] = B[8*(l>>4)+j][l&15], c[r] = C[4*(l>>4)+r][l&15]
+template <class T>
+STAR_DEV f32x4 mfma16(vec<T, 8> a, vec<T, 8> b, f32x4 c) {
+#ifdef STAR_HOSTEMU
+  struct P { float a[8], b[8]; } mine;
+  for (int j = 0; j < 8; ++j) { mine.a[j] = to_f32<T>(a[j]); mine.b[j] = to_f32<T>(b[j]); }
+  auto st = ::star_emu::wave_exchange(&mine, sizeof(mine));
+  const int l = lane_id();
+  for (int r = 0; r < 4; ++r) {
+    const int row = 4 * (l >> 4) + r, col = l & 15;
+    float s = c[r];
+    for (int k = 0; k < 32; ++k) {
+      const P* pa = reinterpret_cast<const P*>(st[row + 16 * (k >> 3)]);
+      const P* pb = reinterpret_cast<const P*>(st[col + 16 * (k >> 3)]);
+      s += pa->a[k & 7] * pb->b[k & 7];
+    }
+    c[r] = s;
+  }
+  return c;
+#else
+  if constexpr (__is_same(T, bf16)) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+#endif
+}
+
+// ---------------------------------------------------------------- LDS-DMA
+// Asynchronous 16-byte-per-lane copy global -> LDS.  Destination is
+// lds_wave_base + lane*16 (lds_wave_base must be wave-uniform); the source
+// address is per lane.  Complete after glds_wait() + a barrier.
+STAR_DEV void glds16(const void* gsrc, void* lds_wave_base) {
+#ifdef STAR_HOSTEMU
+  struct P { const void* src; void* dst; } mine{gsrc, lds_wave_base};
+  auto st = ::star_emu::wave_exchange(&mine, sizeof(mine));
+  const int l = lane_id();
+  // all lanes must agree on the base (wave-uniform) -- check against lane 0 of the live set
+  const P* p0 = nullptr;
+  for (int i = 0; i < 64 && !p0; ++i) {
+    const P* q = reinterpret_cast<const P*>(st[i]);
+    if (q->dst != (void*)~(uintptr_t)0) p0 = q;
+  }
+  if (p0 && p0->dst != lds_wave_base) { fprintf(stderr, "hostemu: glds16 LDS base is not wave-uniform\n"); abort(); }
+  memcpy((char*)lds_wave_base + l * 16, gsrc, 16);
+#else
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+#endif
+}
+STAR_DEV void glds_wait() {
+#ifndef STAR_HOSTEMU
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+
+// ---------------------------------------------------------------- transpose read
+// ds_read_b64_tr_b16: every lane passes the (8-byte aligned) LDS address of 4
+// contiguous 16-bit elements P[lane][0..3]; within each 16-lane group lane i
+// receives R[j] = P[group + 4*j + i/4][i%4]   (verified on MI355X by the probe).
+template <class T>
+STAR_DEV vec<T, 4> lds_read_tr(const void* lds_addr) {
+#ifdef STAR_HOSTEMU
+  uint64_t mine;
+  memcpy(&mine, lds_addr, 8);
+  if (((uintptr_t)lds_addr) & 7) { fprintf(stderr, "hostemu: lds_read_tr address not 8B aligned\n"); abort(); }
+  auto st = ::star_emu::wave_exchange(&mine, 8);
+  const int l = lane_id(), g = l & ~15, i = l & 15;
+  vec<T, 4> r;
+  for (int j = 0; j < 4; ++j) {
+    uint16_t e;
+    memcpy(&e, st[g + 4 * j + i / 4] + 2 * (i % 4), 2);
+    r[j] = __builtin_bit_cast(T, e);
+  }
+  return r;
+#else
+  typedef short s4 __attribute__((ext_vector_type(4)));
+  s4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)lds_addr);
+  return __builtin_bit_cast(vec<T, 4>, t);
+#endif
+}
+
+// ---------------------------------------------------------------- cross-lane
+STAR_DEV float shfl_xor(float v, int mask) {
+#ifdef STAR_HOSTEMU
+  auto st = ::star_emu::wave_exchange(&v, 4);
+  float r;
+  memcpy(&r, st[lane_id() ^ mask], 4);
+  return r;
+#else
+  return __shfl_xor(v, mask, 64);
+#endif
+}
+STAR_DEV float shfl(float v, int src_lane) {
+#ifdef STAR_HOSTEMU
+  auto st = ::star_emu::wave_exchange(&v, 4);
+  float r;
+  memcpy(&r, st[src_lane & 63], 4);
+  return r;
+#else
+  return __shfl(v, src_lane, 64);
+#endif
+}
+// returns {r0, r1}: r0[l<32]=a[l], r0[l>=32]=b[l-32]; r1[l<32]=a[l+32], r1[l>=32]=b[l]
+STAR_DEV u32x2 permlane32_swap(uint32_t a, uint32_t b) {
+#ifdef STAR_HOSTEMU
+  uint32_t mine[2] = {a, b};
+  auto st = ::star_emu::wave_exchange(mine, 8);
+  const int l = lane_id();
+  uint32_t o[2];
+  memcpy(o, st[l ^ 32], 8);
+  u32x2 r;
+  r[0] = l < 32 ? a : o[1];
+  r[1] = l < 32 ? o[0] : b;
+  return r;
+#else
+  auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+  u32x2 o;
+  o[0] = r[0];
+  o[1] = r[1];
+  return o;
+#endif
+}
+STAR_DEV float wave_sum(float v) {
+  for (int m = 32; m >= 1; m >>= 1) v += shfl_xor(v, m);
+  return v;
+}
+STAR_DEV float wave_max(float v) {
+  for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, shfl_xor(v, m));
+  return v;
+}
+
+// ---------------------------------------------------------------- atomics / math
+STAR_DEV void atomic_add(double* p, double v) {
+#ifdef STAR_HOSTEMU
+  *p += v;
+#else
+  atomicAdd(p, v);
+#endif
+}
+STAR_DEV void atomic_add(float* p, float v) {
+#ifdef STAR_HOSTEMU
+  *p += v;
+#else
+  atomicAdd(p, v);
+#endif
+}
+STAR_DEV float fast_exp2(float x) {
+#ifdef STAR_HOSTEMU
+  return exp2f(x);
+#else
+  return __builtin_amdgcn_exp2f(x);
+#endif
+}
+STAR_DEV float fast_rcp(float x) {
+#ifdef STAR_HOSTEMU
+  return 1.0f / x;
+#else
+  return __builtin_amdgcn_rcpf(x);
+#endif
+}
+
+}  // namespace star
+
+// ---------------------------------------------------------------- launch
+#ifdef STAR_HOSTEMU
+#define STAR_LAUNCH(kern, grid, block, smem, stream, ...) \
+  ::star_emu::launch((grid), (block), (smem), [&]() { kern(__VA_ARGS__); })
+#else
+#define STAR_LAUNCH(kern, grid, block, smem, stream, ...)                                              \
+  do {                                                                                                  \
+    if ((smem) > 65536)                                                                                 \
+      (void)hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(smem)); \
+    hipLaunchKernelGGL(kern, (grid), (block), (smem), (stream), __VA_ARGS__);                           \
+  } while (0)
+#endif

@@ -1,0 +1,36 @@
+// rt.h -- minimal runtime shim: device memory / stream calls for the HIP build,
+// plain host memory for the host-emulator build (tools/hostemu, tests only).
+#pragma once
+#include "prim.h"
+#include <cstdlib>
+#include <cstring>
+
+namespace star { namespace rt {
+
+#ifdef STAR_HOSTEMU
+inline int dev_malloc(void** p, size_t bytes) { return posix_memalign(p, 256, bytes ? bytes : 256) ? 1 : 0; }
+inline void dev_free(void* p) { free(p); }
+inline int memset_async(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
+inline int memcpy_h2d(void* d, const void* s, size_t n, hipStream_t) { memcpy(d, s, n); return 0; }
+inline int memcpy_d2h(void* d, const void* s, size_t n, hipStream_t) { memcpy(d, s, n); return 0; }
+inline int memcpy_d2d(void* d, const void* s, size_t n, hipStream_t) { memcpy(d, s, n); return 0; }
+inline int stream_sync(hipStream_t) { return 0; }
+inline int set_device(int) { return 0; }
+inline int device_count() { return 1; }
+inline const char* last_error_string() { return "hostemu"; }
+inline int peek_error() { return 0; }
+#else
+inline int dev_malloc(void** p, size_t bytes) { return hipMalloc(p, bytes ? bytes : 256) == hipSuccess ? 0 : 1; }
+inline void dev_free(void* p) { (void)hipFree(p); }
+inline int memset_async(void* p, int v, size_t n, hipStream_t s) { return hipMemsetAsync(p, v, n, s) != hipSuccess; }
+inline int memcpy_h2d(void* d, const void* s, size_t n, hipStream_t st) { return hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, st) != hipSuccess; }
+inline int memcpy_d2h(void* d, const void* s, size_t n, hipStream_t st) { return hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, st) != hipSuccess; }
+inline int memcpy_d2d(void* d, const void* s, size_t n, hipStream_t st) { return hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, st) != hipSuccess; }
+inline int stream_sync(hipStream_t s) { return hipStreamSynchronize(s) != hipSuccess; }
+inline int set_device(int d) { return hipSetDevice(d) != hipSuccess; }
+inline int device_count() { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+inline const char* last_error_string() { return hipGetErrorString(hipGetLastError()); }
+inline int peek_error() { return hipPeekAtLastError() != hipSuccess; }
+#endif
+
+}}  // namespace star::rt
