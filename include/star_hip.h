@@ -55,6 +55,47 @@ typedef struct star_gemm_desc {
  * (unet_v2v.py:151-155,274,294,500,526,553,612,639,648,717,1005,1025,1209-1220) */
 int star_gemm(star_ctx* ctx, const star_gemm_desc* d);
 
+
+/* replaces: xformers.ops.memory_efficient_attention(q,k,v) for spatial self- and text cross-attention
+ * (unet_v2v.py:158-195).  Q/K/V/O are token matrices; head h uses columns [64h, 64h+64) of each row. */
+typedef struct star_attn_desc {
+  const void* Q; const void* K; const void* V; void* O;
+  int32_t ldq, ldk, ldv, ldo;
+  int64_t bsq, bsk, bsv, bso;        /* batch (frame) strides in elements; 0 = shared by all batches */
+  int32_t Nq, Nk, heads, batch;
+  float scale;
+} star_attn_desc;
+int star_attn_fwd(star_ctx* ctx, const star_attn_desc* d);
+
+/* replaces: the same call on '(b h w) f c' tensors = attention over the frame axis (unet_v2v.py:479-489);
+ * rows are tokens f*HW + pixel, no transposes are materialised. */
+typedef struct star_tattn_desc {
+  const void* Q; const void* K; const void* V; void* O;
+  int32_t ldq, ldk, ldv, ldo;
+  int32_t F, HW, heads;
+  float scale;
+} star_tattn_desc;
+int star_temporal_attn_fwd(star_ctx* ctx, const star_tattn_desc* d);
+
+/* replaces: nn.GroupNorm(32, C) [+ nn.SiLU] on 4-D (per-frame stats) and 5-D (whole-chunk stats) tensors
+ * (unet_v2v.py:268,610,635,1002,1210-1219); rows_per_stat = H*W or F*H*W */
+int star_group_norm(star_ctx* ctx, const void* x, int32_t ldx, void* y, int32_t ldy, const float* gamma,
+                    const float* beta, int32_t rows, int32_t C, int32_t rows_per_stat, float eps, int32_t silu);
+/* replaces: nn.LayerNorm (unet_v2v.py:448-450) with the LIEM gates SpatialAttention (:380-394) /
+ * TemporalLocalAttention (:396-411) fused in front.  mode: 0 plain, 1 linear gate, 2 7x7-map gate, 3 maps only */
+int star_layer_norm(star_ctx* ctx, const void* x, int32_t ldx, void* y, int32_t ldy, const float* gamma,
+                    const float* beta, int32_t rows, int32_t C, float eps, int32_t mode, const float* gate_w,
+                    float* maps, int32_t H, int32_t W);
+/* replaces: torch.cat([x, skip + control], dim=1) (unet_v2v.py:1792) and residual adds */
+int star_concat_add(star_ctx* ctx, const void* a, const void* b, const void* c, void* out, int32_t rows, int32_t C1, int32_t C2);
+int star_add(star_ctx* ctx, const void* a, const void* b, void* out, int64_t n);
+/* replaces: the (b c f h w) <-> (b f) c h w rearranges at the UNet boundary (unet_v2v.py:1772,1808) */
+int star_stem_im2col(star_ctx* ctx, const float* latent, void* out, int32_t Cl, int32_t F, int32_t H, int32_t W);
+int star_rows_to_latent(star_ctx* ctx, const float* rows, float* out, int32_t Cl, int32_t ld, int64_t ntok);
+/* replaces: time_embed / emb_layers Linear on the [1, C] embedding (unet_v2v.py:1340-1342, 626-633) */
+int star_gemv(star_ctx* ctx, const float* x, const void* W, const float* b, float* y, int32_t N, int32_t K, int32_t silu_in, int32_t silu_out);
+int star_cast(star_ctx* ctx, const float* x, void* y, int64_t n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -63,4 +63,44 @@ int star_gemm(star_ctx* h, const star_gemm_desc* d) {
   return op_gemm(&h->c, a);
 }
 
+
+int star_attn_fwd(star_ctx* h, const star_attn_desc* d) {
+  AttnArgs a;
+  a.Q = d->Q; a.K = d->K; a.V = d->V; a.O = d->O;
+  a.ldq = d->ldq; a.ldk = d->ldk; a.ldv = d->ldv; a.ldo = d->ldo;
+  a.bsq = d->bsq; a.bsk = d->bsk; a.bsv = d->bsv; a.bso = d->bso;
+  a.Nq = d->Nq; a.Nk = d->Nk; a.heads = d->heads; a.batch = d->batch; a.scale = d->scale;
+  return op_flash_attn(&h->c, a);
+}
+int star_temporal_attn_fwd(star_ctx* h, const star_tattn_desc* d) {
+  TAttnArgs a;
+  a.Q = d->Q; a.K = d->K; a.V = d->V; a.O = d->O;
+  a.ldq = d->ldq; a.ldk = d->ldk; a.ldv = d->ldv; a.ldo = d->ldo;
+  a.F = d->F; a.HW = d->HW; a.heads = d->heads; a.scale = d->scale;
+  return op_temporal_attn(&h->c, a);
+}
+int star_group_norm(star_ctx* h, const void* x, int32_t ldx, void* y, int32_t ldy, const float* gamma,
+                    const float* beta, int32_t rows, int32_t C, int32_t rows_per_stat, float eps, int32_t silu) {
+  return op_group_norm(&h->c, x, ldx, y, ldy, gamma, beta, rows, C, rows_per_stat, eps, silu != 0);
+}
+int star_layer_norm(star_ctx* h, const void* x, int32_t ldx, void* y, int32_t ldy, const float* gamma,
+                    const float* beta, int32_t rows, int32_t C, float eps, int32_t mode, const float* gate_w,
+                    float* maps, int32_t H, int32_t W) {
+  return op_layer_norm(&h->c, x, ldx, y, ldy, gamma, beta, rows, C, eps, mode, gate_w, maps, H, W);
+}
+int star_concat_add(star_ctx* h, const void* a, const void* b, const void* c, void* out, int32_t rows, int32_t C1, int32_t C2) {
+  return op_concat_add(&h->c, a, b, c, out, rows, C1, C2);
+}
+int star_add(star_ctx* h, const void* a, const void* b, void* out, int64_t n) { return op_add(&h->c, a, b, out, n); }
+int star_stem_im2col(star_ctx* h, const float* latent, void* out, int32_t Cl, int32_t F, int32_t H, int32_t W) {
+  return op_stem_im2col(&h->c, latent, out, Cl, F, H, W);
+}
+int star_rows_to_latent(star_ctx* h, const float* rows, float* out, int32_t Cl, int32_t ld, int64_t ntok) {
+  return op_rows_to_latent(&h->c, rows, out, Cl, ld, ntok);
+}
+int star_gemv(star_ctx* h, const float* x, const void* W, const float* b, float* y, int32_t N, int32_t K, int32_t silu_in, int32_t silu_out) {
+  return op_gemv(&h->c, x, W, b, y, N, K, silu_in != 0, silu_out != 0);
+}
+int star_cast(star_ctx* h, const float* x, void* y, int64_t n) { return op_cast(&h->c, x, y, n); }
+
 }  // extern "C"

@@ -1,0 +1,53 @@
+// attn.cpp -- launchers for the attention kernels (attn.h)
+#include "ops.h"
+#include "attn.h"
+
+namespace star {
+
+template <class T>
+static int launch_flash(Ctx* ctx, const AttnArgs& a) {
+  AttnParams p{};
+  p.Q = a.Q; p.K = a.K; p.V = a.V; p.O = a.O;
+  p.ldq = a.ldq; p.ldk = a.ldk; p.ldv = a.ldv; p.ldo = a.ldo;
+  p.bsq = a.bsq; p.bsk = a.bsk; p.bsv = a.bsv; p.bso = a.bso;
+  p.Nq = a.Nq; p.Nk = a.Nk; p.heads = a.heads; p.batch = a.batch;
+  p.scale_log2e = a.scale * 1.4426950408889634f;
+  p.nqb = (a.Nq + 255) / 256;
+  const int BH = a.batch * a.heads;
+  const long long nblk = 8LL * p.nqb * ((BH + 7) / 8);
+  STAR_LAUNCH((flash_attn_kernel<T>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);
+  return 0;
+}
+
+int op_flash_attn(Ctx* ctx, const AttnArgs& a) {
+  if (a.Nq <= 0 || a.Nk <= 0 || a.batch * a.heads <= 0) return 0;
+  if ((a.ldq | a.ldk | a.ldv | a.ldo) & 7) return ctx->fail("flash_attn: row strides must be multiples of 8 elements");
+  if (ctx->dtype == DT_F16) return launch_flash<f16>(ctx, a);
+  if (ctx->dtype == DT_BF16) return launch_flash<bf16>(ctx, a);
+  return ctx->fail("flash_attn: unsupported dtype");
+}
+
+template <class T>
+static int launch_tattn(Ctx* ctx, const TAttnArgs& a) {
+  TAttnParams p{};
+  p.Q = a.Q; p.K = a.K; p.V = a.V; p.O = a.O;
+  p.ldq = a.ldq; p.ldk = a.ldk; p.ldv = a.ldv; p.ldo = a.ldo;
+  p.F = a.F; p.HW = a.HW; p.heads = a.heads;
+  p.scale_log2e = a.scale * 1.4426950408889634f;
+  const long long items = (long long)a.HW * a.heads;
+  const unsigned grid = (unsigned)((items + 3) / 4);
+  if (a.F <= 32) STAR_LAUNCH((temporal_attn_kernel<T, 1>), dim3(grid), dim3(256), (size_t)(4 * 4096), ctx->stream, p);
+  else STAR_LAUNCH((temporal_attn_kernel<T, 2>), dim3(grid), dim3(256), (size_t)(4 * 8192), ctx->stream, p);
+  return 0;
+}
+
+int op_temporal_attn(Ctx* ctx, const TAttnArgs& a) {
+  if (a.F <= 0 || a.HW <= 0) return 0;
+  if (a.F > 64) return ctx->fail("temporal_attn: at most 64 frames per chunk");
+  if ((a.ldq | a.ldk | a.ldv | a.ldo) & 7) return ctx->fail("temporal_attn: row strides must be multiples of 8 elements");
+  if (ctx->dtype == DT_F16) return launch_tattn<f16>(ctx, a);
+  if (ctx->dtype == DT_BF16) return launch_tattn<bf16>(ctx, a);
+  return ctx->fail("temporal_attn: unsupported dtype");
+}
+
+}  // namespace star

@@ -1,0 +1,360 @@
+// attn.h -- attention kernels of the hot path (head dim 64, no mask, no dropout).
+//
+//  flash_attn_kernel : softmax(Q K^T / sqrt(64)) V with online softmax, for the
+//      spatial self-attention (N = H*W up to 1.3e5 tokens; SURVEY.md K1, reference
+//      unet_v2v.py:158-195 via xformers.ops.memory_efficient_attention) and the
+//      cross-attention to the 77 text tokens (K2; K/V shared by all frames).
+//  temporal_attn_kernel : the per-pixel attention over the frame axis (K3;
+//      unet_v2v.py:479-489), one wavefront per (pixel, head), F <= 64.
+//
+// Both compute S^T = K Q^T with the MFMA operands swapped, so a lane owns one
+// query row: its 32 scores per 64-key tile sit in its own registers, the row max
+// and row sum are lane-local (+ one exchange with lane^32), and the packed
+// probabilities are directly the B operand of O^T = V^T P^T -- no shuffles, no
+// LDS round trip for P.  V^T fragments come from ds_read_b64_tr_b16.
+#pragma once
+#include "prim.h"
+
+namespace star {
+
+struct AttnParams {
+  const void* Q; const void* K; const void* V; void* O;
+  int ldq, ldk, ldv, ldo;            // row strides (elements)
+  long long bsq, bsk, bsv, bso;      // batch strides (elements); bsk = bsv = 0 for a shared context
+  int Nq, Nk, heads, batch;
+  float scale_log2e;                 // softmax scale * log2(e)
+  int nqb;                           // q blocks per (batch, head)
+};
+
+// chunk swizzle shared with gemm.h: 16-B chunk c of 128-B row r lives at chunk c ^ ((r>>1)&7)
+STAR_DEV int swz_off(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
+
+// V^T fragment for MFMA A operand: rows d = 32*db + (lane&31), k-slot j <-> key kb0 + 4h + (j&3) + 8*(j>>2), h = lane>>5
+template <class T>
+STAR_DEV vec<T, 8> load_vt_frag(const char* vbuf, int kb0, int db, int lane) {
+  const int i = lane & 15, g = lane >> 4, h = lane >> 5;
+  const int d = 32 * db + 16 * (g & 1) + 4 * (i & 3);
+  vec<T, 8> out;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const int key = kb0 + 8 * half + 4 * h + (i >> 2);
+    const char* addr = vbuf + swz_off(key, d >> 3) + (d & 7) * 2;
+    vec<T, 4> r = lds_read_tr<T>(addr);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) out[half * 4 + e] = r[e];
+  }
+  return out;
+}
+
+template <class T>
+STAR_GLOBAL void STAR_LAUNCH_BOUNDS(256, 2)
+flash_attn_kernel(const AttnParams p) {
+  constexpr int QW = 64;          // q rows per wave (two 32-row blocks)
+  constexpr int QB = 256;         // q rows per workgroup
+  constexpr int KT = 64;          // keys per tile
+  constexpr int TILE = KT * 128;  // bytes of one K or V tile in LDS
+  char* smem = dyn_smem();        // [2][K tile | V tile]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h2 = lane >> 5, lq = lane & 31;
+
+  // XCD-aware mapping: the blocks resident on one XCD (bid % 8) share one (batch, head) => K/V stay in that XCD's L2
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int bh = xcd + 8 * (slot / p.nqb);
+  const int qb = slot % p.nqb;
+  const int BH = p.batch * p.heads;
+  if (bh >= BH) return;
+  const int b = bh / p.heads, hd = bh % p.heads;
+
+  const T* __restrict__ Qg = (const T*)p.Q + (size_t)b * p.bsq + hd * 64;
+  const T* __restrict__ Kg = (const T*)p.K + (size_t)b * p.bsk + hd * 64;
+  const T* __restrict__ Vg = (const T*)p.V + (size_t)b * p.bsv + hd * 64;
+  T* __restrict__ Og = (T*)p.O + (size_t)b * p.bso + hd * 64;
+
+  // ---- Q fragments (B operand: col = q row, k = d)
+  vec<T, 8> qf[2][4];
+  const int q_base = qb * QB + wave * QW;
+#pragma unroll
+  for (int qi = 0; qi < 2; ++qi) {
+    int q = q_base + qi * 32 + lq;
+    if (q > p.Nq - 1) q = p.Nq - 1;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      qf[qi][ks] = *reinterpret_cast<const vec<T, 8>*>(Qg + (size_t)q * p.ldq + ks * 16 + h2 * 8);
+  }
+
+  // ---- K/V tile loaders: 64 rows x 8 chunks = 512 chunks per tile, 2 per thread each
+  const int pos = tid & 7;
+  auto stage = [&](int t, int buf) {
+    char* kbuf = smem + buf * 2 * TILE;
+    char* vbuf = kbuf + TILE;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r = (j * 256 + tid) >> 3;
+      const int c = pos ^ ((r >> 1) & 7);
+      int key = t * KT + r;
+      if (key > p.Nk - 1) key = p.Nk - 1;
+      glds16(Kg + (size_t)key * p.ldk + c * 8, kbuf + (size_t)(j * 256 + wave * 64) * 16);
+      glds16(Vg + (size_t)key * p.ldv + c * 8, vbuf + (size_t)(j * 256 + wave * 64) * 16);
+    }
+  };
+
+  f32x16 oacc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[a][c][r] = 0.f;
+  float m_run[2] = {-1e30f, -1e30f};   // running max (scaled, log2 domain)
+  float l_run[2] = {0.f, 0.f};         // this lane's partial row sum
+
+  const int nt = (p.Nk + KT - 1) / KT;
+  const float c = p.scale_log2e;
+  stage(0, 0);
+  for (int t = 0; t < nt; ++t) {
+    glds_wait();
+    block_sync();
+    if (t + 1 < nt) stage(t + 1, (t + 1) & 1);
+    const char* kbuf = smem + (t & 1) * 2 * TILE;
+    const char* vbuf = kbuf + TILE;
+
+    // ---- S^T = K Q^T : sacc[qi][kvb], lane: q = qi*32+lq, key = 32*kvb + (r&3) + 8*(r>>2) + 4*h2
+    f32x16 sacc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[a][kb][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        const int R = kb * 32 + lq;
+        const vec<T, 8> kf = *reinterpret_cast<const vec<T, 8>*>(kbuf + swz_off(R, ks * 2 + h2));
+#pragma unroll
+        for (int qi = 0; qi < 2; ++qi) sacc[qi][kb] = mfma32<T>(kf, qf[qi][ks], sacc[qi][kb]);
+      }
+    }
+    // ---- mask the key tail of the last tile
+    if (t == nt - 1 && (p.Nk & (KT - 1))) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = t * KT + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
+          if (key >= p.Nk) { sacc[0][kb][r] = -1e30f; sacc[1][kb][r] = -1e30f; }
+        }
+    }
+    // ---- online softmax, P packed as the B operand of the PV MFMA
+    vec<T, 8> pf[2][4];
+#pragma unroll
+    for (int qi = 0; qi < 2; ++qi) {
+      float mx = sacc[qi][0][0];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[qi][kb][r]);
+      mx = fmaxf(mx, shfl_xor(mx, 32));
+      const float m_new = fmaxf(m_run[qi], mx * c);
+      const float alpha = fast_exp2(m_run[qi] - m_new);
+      m_run[qi] = m_new;
+      float ls = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          vec<T, 8> pk;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float pv = fast_exp2(sacc[qi][kb][8 * u + e] * c - m_new);
+            ls += pv;
+            pk[e] = from_f32<T>(pv);
+          }
+          pf[qi][kb * 2 + u] = pk;
+        }
+      l_run[qi] = l_run[qi] * alpha + ls;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[qi][db][r] *= alpha;
+    }
+    // ---- O^T += V^T P^T
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        const vec<T, 8> vf = load_vt_frag<T>(vbuf, tt * 16, db, lane);
+#pragma unroll
+        for (int qi = 0; qi < 2; ++qi) oacc[qi][db] = mfma32<T>(vf, pf[qi][tt], oacc[qi][db]);
+      }
+    }
+  }
+
+  // ---- epilogue: O = oacc / l ; lane holds d = 32*db + 8*g + 4*h2 + (0..3); pair groups into 16-B stores
+#pragma unroll
+  for (int qi = 0; qi < 2; ++qi) {
+    const float l = l_run[qi] + shfl_xor(l_run[qi], 32);
+    const float inv = 1.0f / l;
+    const int q = q_base + qi * 32 + lq;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {  // group pair (2a, 2a+1)
+        uint32_t w0[2], w1[2];      // packed T x4 of group 2a / 2a+1
+#pragma unroll
+        for (int gg = 0; gg < 2; ++gg) {
+          vec<T, 4> o4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o4[e] = from_f32<T>(oacc[qi][db][(2 * a + gg) * 4 + e] * inv);
+          u32x2 pk = __builtin_bit_cast(u32x2, o4);
+          if (gg == 0) { w0[0] = pk[0]; w0[1] = pk[1]; } else { w1[0] = pk[0]; w1[1] = pk[1]; }
+        }
+        const u32x2 s0 = permlane32_swap(w0[0], w1[0]);
+        const u32x2 s1 = permlane32_swap(w0[1], w1[1]);
+        // lower lane: d = 32db + 16a + 0..7 ; upper lane: d = 32db + 16a + 8..15
+        u32x4 out;
+        out[0] = s0[0]; out[1] = s1[0]; out[2] = s0[1]; out[3] = s1[1];
+        if (q < p.Nq) *reinterpret_cast<u32x4*>(Og + (size_t)q * p.ldo + 32 * db + 16 * a + 8 * h2) = out;
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+struct TAttnParams {
+  const void* Q; const void* K; const void* V; void* O;
+  int ldq, ldk, ldv, ldo;   // row strides (elements) of the [F*HW, *] token matrices
+  int F, HW, heads;
+  float scale_log2e;
+};
+
+// one wavefront per (pixel, head); NB = number of 32-frame blocks (1: F<=32, 2: F<=64)
+template <class T, int NB>
+STAR_GLOBAL void STAR_LAUNCH_BOUNDS(256)
+temporal_attn_kernel(const TAttnParams p) {
+  char* smem = dyn_smem();
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h2 = lane >> 5, lq = lane & 31;
+  const long long item = (long long)blockIdx.x * 4 + wave;
+  const long long nitems = (long long)p.HW * p.heads;
+  const bool active = item < nitems;
+  const long long it = active ? item : nitems - 1;
+  const int pix = (int)(it / p.heads), hd = (int)(it % p.heads);
+  char* vbuf = smem + wave * (NB * 32 * 128);
+
+  const T* __restrict__ Qg = (const T*)p.Q + hd * 64;
+  const T* __restrict__ Kg = (const T*)p.K + hd * 64;
+  const T* __restrict__ Vg = (const T*)p.V + hd * 64;
+  T* __restrict__ Og = (T*)p.O + hd * 64;
+
+  // ---- stage V (frames x 64) into this wave's LDS slab (swizzled rows), 8 rows per LDS-DMA
+#pragma unroll
+  for (int j = 0; j < NB * 4; ++j) {
+    const int r = j * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    int f = r;
+    if (f > p.F - 1) f = p.F - 1;
+    glds16(Vg + ((size_t)f * p.HW + pix) * p.ldv + c * 8, vbuf + j * 1024);
+  }
+  // ---- Q / K fragments straight from global
+  vec<T, 8> qf[NB][4], kf[NB][4];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    int f = nb * 32 + lq;
+    if (f > p.F - 1) f = p.F - 1;
+    const size_t row = (size_t)f * p.HW + pix;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      qf[nb][ks] = *reinterpret_cast<const vec<T, 8>*>(Qg + row * p.ldq + ks * 16 + h2 * 8);
+      kf[nb][ks] = *reinterpret_cast<const vec<T, 8>*>(Kg + row * p.ldk + ks * 16 + h2 * 8);
+    }
+  }
+  // ---- S^T[key][q]
+  f32x16 sacc[NB][NB];  // [qi][kb]
+#pragma unroll
+  for (int qi = 0; qi < NB; ++qi)
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[qi][kb][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) sacc[qi][kb] = mfma32<T>(kf[kb][ks], qf[qi][ks], sacc[qi][kb]);
+    }
+  const float c = p.scale_log2e;
+  vec<T, 8> pf[NB][NB * 2];
+  float linv[NB];
+#pragma unroll
+  for (int qi = 0; qi < NB; ++qi) {
+    float mx = -1e30f;
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
+        if (key >= p.F) sacc[qi][kb][r] = -1e30f;
+        mx = fmaxf(mx, sacc[qi][kb][r]);
+      }
+    mx = fmaxf(mx, shfl_xor(mx, 32)) * c;
+    float ls = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        vec<T, 8> pk;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float pv = fast_exp2(sacc[qi][kb][8 * u + e] * c - mx);
+          ls += pv;
+          pk[e] = from_f32<T>(pv);
+        }
+        pf[qi][kb * 2 + u] = pk;
+      }
+    ls += shfl_xor(ls, 32);
+    linv[qi] = 1.0f / ls;
+  }
+  glds_wait();
+  block_sync();
+  // ---- O^T = V^T P^T
+  f32x16 oacc[NB][2];
+#pragma unroll
+  for (int qi = 0; qi < NB; ++qi)
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[qi][db][r] = 0.f;
+#pragma unroll
+  for (int tt = 0; tt < NB * 2; ++tt)
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+      const vec<T, 8> vf = load_vt_frag<T>(vbuf, tt * 16, db, lane);
+#pragma unroll
+      for (int qi = 0; qi < NB; ++qi) oacc[qi][db] = mfma32<T>(vf, pf[qi][tt], oacc[qi][db]);
+    }
+#pragma unroll
+  for (int qi = 0; qi < NB; ++qi) {
+    const int f = qi * 32 + lq;
+    const size_t row = (size_t)(f < p.F ? f : p.F - 1) * p.HW + pix;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        uint32_t w0[2], w1[2];
+#pragma unroll
+        for (int gg = 0; gg < 2; ++gg) {
+          vec<T, 4> o4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o4[e] = from_f32<T>(oacc[qi][db][(2 * a + gg) * 4 + e] * linv[qi]);
+          u32x2 pk = __builtin_bit_cast(u32x2, o4);
+          if (gg == 0) { w0[0] = pk[0]; w0[1] = pk[1]; } else { w1[0] = pk[0]; w1[1] = pk[1]; }
+        }
+        const u32x2 s0 = permlane32_swap(w0[0], w1[0]);
+        const u32x2 s1 = permlane32_swap(w0[1], w1[1]);
+        u32x4 out;
+        out[0] = s0[0]; out[1] = s1[0]; out[2] = s0[1]; out[3] = s1[1];
+        if (active && f < p.F) *reinterpret_cast<u32x4*>(Og + row * p.ldo + 32 * db + 16 * a + 8 * h2) = out;
+      }
+  }
+}
+
+}  // namespace star

@@ -1,5 +1,6 @@
 // gemm.cpp -- tile selection + launch for gemm_kernel (see gemm.h).
 #include "ops.h"
+#include "gemm.h"
 
 namespace star {
 

@@ -1,0 +1,122 @@
+// norm.cpp -- launchers for norm.h
+#include "ops.h"
+#include "norm.h"
+
+namespace star {
+
+static inline unsigned ew_grid(long long total, int block = 256) {
+  long long g = (total + block - 1) / block;
+  if (g > 256 * 16) g = 256 * 16;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+template <class T>
+static int gn_t(Ctx* ctx, const void* x, int ldx, void* y, int ldy, const float* gamma, const float* beta,
+                int rows, int C, int rows_per_stat, float eps, bool silu) {
+  const int nstat = rows / rows_per_stat;
+  Buf sums(ctx, (size_t)nstat * 64 * sizeof(double));
+  Buf ab(ctx, (size_t)nstat * C * 2 * sizeof(float));
+  if (!sums.p || !ab.p) return ctx->fail("group_norm: out of device memory");
+  rt::memset_async(sums.p, 0, (size_t)nstat * 64 * sizeof(double), ctx->stream);
+  const int CC8 = C / 8;
+  int RL = 256 / CC8; if (RL < 1) RL = 1;
+  const int nthreads = CC8 * RL;
+  // slab: enough rows per block to amortise the reduction, enough blocks to fill the chip
+  int slab = 256;
+  while ((long long)((rows_per_stat + slab - 1) / slab) * nstat < 1024 && slab > 32) slab >>= 1;
+  GnStatsParams sp{x, ldx, C, rows_per_stat, slab, sums.as<double>()};
+  dim3 grid((unsigned)((rows_per_stat + slab - 1) / slab), (unsigned)nstat);
+  STAR_LAUNCH((gn_stats_kernel<T>), grid, dim3(nthreads), (size_t)256, ctx->stream, sp);
+  GnFinalizeParams fp{sums.as<double>(), gamma, beta, ab.as<float>(), C, nstat, (double)rows_per_stat * (C / 32), eps};
+  STAR_LAUNCH(gn_finalize_kernel, dim3((unsigned)((nstat * C + 255) / 256)), dim3(256), (size_t)0, ctx->stream, fp);
+  GnApplyParams ap{x, y, ab.as<float>(), ldx, ldy, C, rows, rows_per_stat, silu ? 1 : 0};
+  STAR_LAUNCH((gn_apply_kernel<T>), dim3(ew_grid((long long)rows * CC8)), dim3(256), (size_t)0, ctx->stream, ap);
+  return 0;
+}
+
+int op_group_norm(Ctx* ctx, const void* x, int ldx, void* y, int ldy, const float* gamma, const float* beta,
+                  int rows, int C, int rows_per_stat, float eps, bool silu) {
+  if (C % 32 || C % 8) return ctx->fail("group_norm: C must be a multiple of 32");
+  if (rows % rows_per_stat) return ctx->fail("group_norm: rows not a multiple of rows_per_stat");
+  if ((ldx | ldy) & 7) return ctx->fail("group_norm: row strides must be multiples of 8");
+  if (C / 8 > 1024) return ctx->fail("group_norm: C too large");
+  if (ctx->dtype == DT_F16) return gn_t<f16>(ctx, x, ldx, y, ldy, gamma, beta, rows, C, rows_per_stat, eps, silu);
+  return gn_t<bf16>(ctx, x, ldx, y, ldy, gamma, beta, rows, C, rows_per_stat, eps, silu);
+}
+
+template <class T>
+static int ln_t(Ctx* ctx, const LnParams& p) {
+  const int CC8 = p.C / 8;
+  const int per_lane = (CC8 + 63) / 64;
+  dim3 grid((unsigned)((p.rows + 3) / 4)), block(256);
+  if (per_lane <= 1) STAR_LAUNCH((ln_kernel<T, 1>), grid, block, (size_t)0, ctx->stream, p);
+  else if (per_lane <= 2) STAR_LAUNCH((ln_kernel<T, 2>), grid, block, (size_t)0, ctx->stream, p);
+  else if (per_lane <= 3) STAR_LAUNCH((ln_kernel<T, 3>), grid, block, (size_t)0, ctx->stream, p);
+  else if (per_lane <= 5) STAR_LAUNCH((ln_kernel<T, 5>), grid, block, (size_t)0, ctx->stream, p);
+  else return ctx->fail("layer_norm: C too large (max 2560)");
+  return 0;
+}
+
+int op_layer_norm(Ctx* ctx, const void* x, int ldx, void* y, int ldy, const float* gamma, const float* beta,
+                  int rows, int C, float eps, int mode, const float* gate_w, float* maps, int H, int W) {
+  if (C % 8) return ctx->fail("layer_norm: C must be a multiple of 8");
+  if ((ldx | ldy) & 7) return ctx->fail("layer_norm: row strides must be multiples of 8");
+  if (rows <= 0) return 0;
+  LnParams p{x, y, gamma, beta, gate_w, maps, ldx, ldy, C, rows, H, W, eps, mode};
+  if (ctx->dtype == DT_F16) return ln_t<f16>(ctx, p);
+  return ln_t<bf16>(ctx, p);
+}
+
+int op_concat_add(Ctx* ctx, const void* a, const void* b, const void* c, void* out, int rows, int C1, int C2) {
+  if ((C1 | C2) & 7) return ctx->fail("concat_add: channel counts must be multiples of 8");
+  ConcatParams p{a, b, c, out, C1, C2, rows};
+  const unsigned g = ew_grid((long long)rows * ((C1 + C2) / 8));
+  if (ctx->dtype == DT_F16) STAR_LAUNCH((concat_add_kernel<f16>), dim3(g), dim3(256), (size_t)0, ctx->stream, p);
+  else STAR_LAUNCH((concat_add_kernel<bf16>), dim3(g), dim3(256), (size_t)0, ctx->stream, p);
+  return 0;
+}
+
+int op_add(Ctx* ctx, const void* a, const void* b, void* out, long long n) {
+  if (n & 7) return ctx->fail("add: n must be a multiple of 8");
+  AddParams p{a, b, out, n / 8};
+  const unsigned g = ew_grid(n / 8);
+  if (ctx->dtype == DT_F16) STAR_LAUNCH((add_kernel<f16>), dim3(g), dim3(256), (size_t)0, ctx->stream, p);
+  else STAR_LAUNCH((add_kernel<bf16>), dim3(g), dim3(256), (size_t)0, ctx->stream, p);
+  return 0;
+}
+
+int op_stem_im2col(Ctx* ctx, const float* latent, void* out, int Cl, int F, int H, int W) {
+  if (9 * Cl > 64) return ctx->fail("stem_im2col: at most 7 latent channels");
+  StemIm2colParams p{latent, out, Cl, F, H, W};
+  const unsigned g = ew_grid((long long)F * H * W * 8);
+  if (ctx->dtype == DT_F16) STAR_LAUNCH((stem_im2col_kernel<f16>), dim3(g), dim3(256), (size_t)0, ctx->stream, p);
+  else STAR_LAUNCH((stem_im2col_kernel<bf16>), dim3(g), dim3(256), (size_t)0, ctx->stream, p);
+  return 0;
+}
+
+int op_rows_to_latent(Ctx* ctx, const float* rows, float* out, int Cl, int ld, long long ntok) {
+  RowsToLatentParams p{rows, out, Cl, ld, ntok};
+  STAR_LAUNCH(rows_to_latent_kernel, dim3(ew_grid(ntok * Cl)), dim3(256), (size_t)0, ctx->stream, p);
+  return 0;
+}
+
+int op_gemv(Ctx* ctx, const float* x, const void* W, const float* b, float* y, int N, int K, bool silu_in, bool silu_out) {
+  if (K & 7) return ctx->fail("gemv: K must be a multiple of 8");
+  GemvParams p{x, W, b, y, N, K, silu_in ? 1 : 0, silu_out ? 1 : 0};
+  dim3 grid((unsigned)((N + 3) / 4)), block(256);
+  if (ctx->dtype == DT_F16) STAR_LAUNCH((gemv_kernel<f16>), grid, block, (size_t)0, ctx->stream, p);
+  else STAR_LAUNCH((gemv_kernel<bf16>), grid, block, (size_t)0, ctx->stream, p);
+  return 0;
+}
+
+int op_cast(Ctx* ctx, const float* x, void* y, long long n) {
+  if (n & 7) return ctx->fail("cast: n must be a multiple of 8");
+  CastParams p{x, y, n / 8};
+  const unsigned g = ew_grid(n / 8);
+  if (ctx->dtype == DT_F16) STAR_LAUNCH((cast_kernel<f16>), dim3(g), dim3(256), (size_t)0, ctx->stream, p);
+  else STAR_LAUNCH((cast_kernel<bf16>), dim3(g), dim3(256), (size_t)0, ctx->stream, p);
+  return 0;
+}
+
+}  // namespace star

@@ -1,0 +1,312 @@
+// norm.h -- bandwidth-bound kernels of the hot path: GroupNorm (4-D per-frame and
+// 5-D whole-chunk statistics), LayerNorm with the LIEM gates fused in
+// (K8, K9), SiLU, residual / concat plumbing (K10), the tiny time-embedding GEMVs
+// (K11) and the latent layout conversions at the UNet boundary.
+// All activations are channels-last [tokens, C]; loads/stores are 16 B per lane.
+#pragma once
+#include "prim.h"
+#include "optypes.h"
+
+namespace star {
+
+STAR_DEV float silu_f(float x) { return x * fast_rcp(1.0f + fast_exp2(-1.4426950408889634f * x)); }
+STAR_DEV float sigmoid_f(float x) { return fast_rcp(1.0f + fast_exp2(-1.4426950408889634f * x)); }
+
+// ------------------------------------------------------------------ GroupNorm statistics
+// reference: nn.GroupNorm(32, C) on (b f) c h w  [stats per frame]  unet_v2v.py:610,635,268
+//            nn.GroupNorm(32, C) on  b c f h w   [stats over the whole chunk] unet_v2v.py:1210-1219,1002
+struct GnStatsParams {
+  const void* x; int ld; int C; int rows_per_stat; int slab; double* sums;  // sums[nstat][32][2]
+};
+template <class T>
+STAR_GLOBAL void gn_stats_kernel(const GnStatsParams p) {
+  float* gs = reinterpret_cast<float*>(dyn_smem());  // [32][2]
+  const int t = threadIdx.x;
+  const int CC8 = p.C >> 3;
+  const int RL = blockDim.x / CC8;
+  const int cc = t % CC8, rl = t / CC8;
+  const int stat = blockIdx.y;
+  const int r0 = blockIdx.x * p.slab;
+  int r1 = r0 + p.slab;
+  if (r1 > p.rows_per_stat) r1 = p.rows_per_stat;
+  if (t < 64) gs[t] = 0.f;
+  block_sync();
+  float s[8], ss[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; }
+  const T* __restrict__ base = (const T*)p.x + ((size_t)stat * p.rows_per_stat) * p.ld + cc * 8;
+  if (rl < RL) {
+    for (int r = r0 + rl; r < r1; r += RL) {
+      const vec<T, 8> v = *reinterpret_cast<const vec<T, 8>*>(base + (size_t)r * p.ld);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float f = to_f32<T>(v[e]); s[e] += f; ss[e] += f * f; }
+    }
+    const int cg = p.C >> 5;
+    int g = (cc * 8) / cg;
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int ge = (cc * 8 + e) / cg;
+      if (ge != g) { atomic_add(&gs[2 * g], a); atomic_add(&gs[2 * g + 1], b); a = 0.f; b = 0.f; g = ge; }
+      a += s[e]; b += ss[e];
+    }
+    atomic_add(&gs[2 * g], a); atomic_add(&gs[2 * g + 1], b);
+  }
+  block_sync();
+  if (t < 64) atomic_add(&p.sums[(size_t)stat * 64 + t], (double)gs[t]);
+}
+
+// sums -> per-(stat, channel) affine (a, b): y = x*a + b
+struct GnFinalizeParams {
+  const double* sums; const float* gamma; const float* beta; float* ab;  // ab[nstat][C][2]
+  int C; int nstat; double count; float eps;
+};
+STAR_GLOBAL void gn_finalize_kernel(const GnFinalizeParams p) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.nstat * p.C) return;
+  const int stat = i / p.C, c = i - stat * p.C;
+  const int g = c / (p.C >> 5);
+  const double mean = p.sums[(size_t)stat * 64 + 2 * g] / p.count;
+  double var = p.sums[(size_t)stat * 64 + 2 * g + 1] / p.count - mean * mean;
+  if (var < 0) var = 0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
+  const float a = p.gamma[c] * rstd;
+  p.ab[2 * (size_t)i] = a;
+  p.ab[2 * (size_t)i + 1] = p.beta[c] - (float)mean * a;
+}
+
+struct GnApplyParams {
+  const void* x; void* y; const float* ab; int ldx, ldy, C; int rows; int rows_per_stat; int silu;
+};
+template <class T>
+STAR_GLOBAL void gn_apply_kernel(const GnApplyParams p) {
+  const int CC8 = p.C >> 3;
+  const long long total = (long long)p.rows * CC8;
+  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long long)gridDim.x * blockDim.x) {
+    const int row = (int)(q / CC8), cc = (int)(q - (long long)row * CC8);
+    const int stat = row / p.rows_per_stat;
+    const vec<T, 8> v = *reinterpret_cast<const vec<T, 8>*>((const T*)p.x + (size_t)row * p.ldx + cc * 8);
+    const float* ab = p.ab + 2 * ((size_t)stat * p.C + cc * 8);
+    const f32x4 ab0 = *reinterpret_cast<const f32x4*>(ab), ab1 = *reinterpret_cast<const f32x4*>(ab + 4),
+                ab2 = *reinterpret_cast<const f32x4*>(ab + 8), ab3 = *reinterpret_cast<const f32x4*>(ab + 12);
+    const float av[8] = {ab0[0], ab0[2], ab1[0], ab1[2], ab2[0], ab2[2], ab3[0], ab3[2]};
+    const float bv[8] = {ab0[1], ab0[3], ab1[1], ab1[3], ab2[1], ab2[3], ab3[1], ab3[3]};
+    vec<T, 8> o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float f = to_f32<T>(v[e]) * av[e] + bv[e];
+      if (p.silu) f = silu_f(f);
+      o[e] = from_f32<T>(f);
+    }
+    *reinterpret_cast<vec<T, 8>*>((T*)p.y + (size_t)row * p.ldy + cc * 8) = o;
+  }
+}
+
+// ------------------------------------------------------------------ LayerNorm rows (+ LIEM gates)
+// reference: BasicTransformerBlock.norm1/2/3 (unet_v2v.py:448-450), LIEM SpatialAttention (:380-394)
+//            and TemporalLocalAttention (:396-411) applied in front of norm1 / norm2 (:466-490).
+struct LnParams {
+  const void* x; void* y; const float* gamma; const float* beta;
+  const float* gate_w;   // LINEAR: [2]; MAP: [2][7][7]
+  float* maps;           // [tokens][2] (written by STATS_ONLY, read by GATE_MAP)
+  int ldx, ldy, C, rows; int H, W;  // H,W: image size for GATE_MAP (token = (f*H + y)*W + x)
+  float eps; int mode;
+};
+template <class T, int MAXCH>   // MAXCH: 16-B chunks per lane (C <= 512*MAXCH)
+STAR_GLOBAL void ln_kernel(const LnParams p) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const bool active = row < p.rows;
+  const int rr = active ? row : p.rows - 1;
+  const int CC8 = p.C >> 3;
+  float v[MAXCH][8];
+  float mx = -3.0e38f, sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXCH; ++i) {
+    const int cc = lane + 64 * i;
+    if (cc < CC8) {
+      const vec<T, 8> t = *reinterpret_cast<const vec<T, 8>*>((const T*)p.x + (size_t)rr * p.ldx + cc * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { v[i][e] = to_f32<T>(t[e]); mx = fmaxf(mx, v[i][e]); sum += v[i][e]; }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+    }
+  }
+  sum = wave_sum(sum);
+  const float inv_c = 1.0f / (float)p.C;
+  float mean = sum * inv_c;
+  if (p.mode != LN_PLAIN) mx = wave_max(mx);
+  if (p.mode == LN_STATS_ONLY) {
+    if (active && lane == 0) { p.maps[2 * (size_t)row] = mx; p.maps[2 * (size_t)row + 1] = mean; }
+    return;
+  }
+  float gate = 1.0f;
+  if (p.mode == LN_GATE_LINEAR) {
+    gate = sigmoid_f(p.gate_w[0] * mx + p.gate_w[1] * mean);
+  } else if (p.mode == LN_GATE_MAP) {
+    const int hw = p.H * p.W;
+    const int f = rr / hw, rem = rr - f * hw;
+    const int y = rem / p.W, x = rem - y * p.W;
+    float acc = 0.f;
+    for (int tap = lane; tap < 98; tap += 64) {
+      const int ch = tap / 49, k = tap - ch * 49;
+      const int dy = k / 7 - 3, dx = k - (k / 7) * 7 - 3;
+      const int yy = y + dy, xx = x + dx;
+      if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W)
+        acc += p.gate_w[tap] * p.maps[2 * ((size_t)f * hw + (size_t)yy * p.W + xx) + ch];
+    }
+    gate = sigmoid_f(wave_sum(acc));
+  }
+  if (p.mode != LN_PLAIN) {
+    mean *= gate;
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[i][e] *= gate;
+  }
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXCH; ++i) {
+    const int cc = lane + 64 * i;
+    if (cc < CC8) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; sq += d * d; }
+    }
+  }
+  sq = wave_sum(sq);
+  const float rstd = 1.0f / sqrtf(sq * inv_c + p.eps);
+  if (!active) return;
+#pragma unroll
+  for (int i = 0; i < MAXCH; ++i) {
+    const int cc = lane + 64 * i;
+    if (cc < CC8) {
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.gamma + cc * 8), g1 = *reinterpret_cast<const f32x4*>(p.gamma + cc * 8 + 4);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.beta + cc * 8), b1 = *reinterpret_cast<const f32x4*>(p.beta + cc * 8 + 4);
+      vec<T, 8> o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[e] = from_f32<T>((v[i][e] - mean) * rstd * g0[e] + b0[e]);
+        o[4 + e] = from_f32<T>((v[i][4 + e] - mean) * rstd * g1[e] + b1[e]);
+      }
+      *reinterpret_cast<vec<T, 8>*>((T*)p.y + (size_t)row * p.ldy + cc * 8) = o;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ elementwise plumbing
+// out[row] = concat(a[row][0:C1], b[row][0:C2] (+ c[row][0:C2]))   (unet_v2v.py:1792 torch.cat([x, xs.pop() + control.pop()]))
+struct ConcatParams { const void* a; const void* b; const void* c; void* out; int C1, C2, rows; };
+template <class T>
+STAR_GLOBAL void concat_add_kernel(const ConcatParams p) {
+  const int CT8 = (p.C1 + p.C2) >> 3, C18 = p.C1 >> 3;
+  const long long total = (long long)p.rows * CT8;
+  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long long)gridDim.x * blockDim.x) {
+    const int row = (int)(q / CT8), cc = (int)(q - (long long)row * CT8);
+    vec<T, 8> o;
+    if (cc < C18) {
+      o = *reinterpret_cast<const vec<T, 8>*>((const T*)p.a + (size_t)row * p.C1 + cc * 8);
+    } else {
+      const size_t off = (size_t)row * p.C2 + (cc - C18) * 8;
+      o = *reinterpret_cast<const vec<T, 8>*>((const T*)p.b + off);
+      if (p.c) {
+        const vec<T, 8> c = *reinterpret_cast<const vec<T, 8>*>((const T*)p.c + off);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = from_f32<T>(to_f32<T>(o[e]) + to_f32<T>(c[e]));
+      }
+    }
+    *reinterpret_cast<vec<T, 8>*>((T*)p.out + (size_t)row * (p.C1 + p.C2) + cc * 8) = o;
+  }
+}
+
+// out = a + b (same shape, n multiple of 8)
+struct AddParams { const void* a; const void* b; void* out; long long n8; };
+template <class T>
+STAR_GLOBAL void add_kernel(const AddParams p) {
+  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < p.n8; q += (long long)gridDim.x * blockDim.x) {
+    const vec<T, 8> a = reinterpret_cast<const vec<T, 8>*>(p.a)[q], b = reinterpret_cast<const vec<T, 8>*>(p.b)[q];
+    vec<T, 8> o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = from_f32<T>(to_f32<T>(a[e]) + to_f32<T>(b[e]));
+    reinterpret_cast<vec<T, 8>*>(p.out)[q] = o;
+  }
+}
+
+// latent [1, Cl, F, H, W] (fp32) -> im2col rows [F*H*W][64] of the 3x3 pad-1 stem conv: column tap*Cl + c, rest 0
+// (unet_v2v.py:1353 nn.Conv2d(in_dim, dim, 3, padding=1) and :2128 input_hint_block)
+struct StemIm2colParams { const float* x; void* out; int Cl, F, H, W; };
+template <class T>
+STAR_GLOBAL void stem_im2col_kernel(const StemIm2colParams p) {
+  const long long rows = (long long)p.F * p.H * p.W;
+  const long long total = rows * 8;  // 8 chunks of 8 columns
+  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long long)gridDim.x * blockDim.x) {
+    const long long row = q >> 3; const int ch = (int)(q & 7);
+    const int hw = p.H * p.W;
+    const int f = (int)(row / hw), rem = (int)(row - (long long)f * hw);
+    const int y = rem / p.W, x = rem - y * p.W;
+    vec<T, 8> o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int col = ch * 8 + e;
+      float v = 0.f;
+      if (col < 9 * p.Cl) {
+        const int tap = col / p.Cl, c = col - tap * p.Cl;
+        const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+        if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) v = p.x[(((size_t)c * p.F + f) * p.H + yy) * p.W + xx];
+      }
+      o[e] = from_f32<T>(v);
+    }
+    *reinterpret_cast<vec<T, 8>*>((T*)p.out + row * 64 + ch * 8) = o;
+  }
+}
+
+// rows [F*H*W][ld] fp32 (first Cl columns) -> latent [1, Cl, F, H, W] fp32
+struct RowsToLatentParams { const float* rows; float* out; int Cl, ld; long long ntok; };
+STAR_GLOBAL void rows_to_latent_kernel(const RowsToLatentParams p) {
+  const long long total = p.ntok * p.Cl;
+  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(q / p.ntok); const long long tok = q - (long long)c * p.ntok;
+    p.out[q] = p.rows[tok * p.ld + c];
+  }
+}
+
+// y[n] = act_out( sum_k W[n][k] * act_in(x[k]) + b[n] ), fp32 vectors, T weights: one wavefront per output
+// (time_embed MLP unet_v2v.py:1340-1342 and ResBlock.emb_layers :626-633; M = 1 because batch = 1)
+struct GemvParams { const float* x; const void* W; const float* b; float* y; int N, K; int silu_in, silu_out; };
+template <class T>
+STAR_GLOBAL void gemv_kernel(const GemvParams p) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (n >= p.N) return;
+  const T* __restrict__ w = (const T*)p.W + (size_t)n * p.K;
+  float acc = 0.f;
+  for (int k = lane * 8; k < p.K; k += 512) {
+    const vec<T, 8> wv = *reinterpret_cast<const vec<T, 8>*>(w + k);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float xv = p.x[k + e];
+      if (p.silu_in) xv = silu_f(xv);
+      acc += to_f32<T>(wv[e]) * xv;
+    }
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) {
+    float r = acc + (p.b ? p.b[n] : 0.f);
+    if (p.silu_out) r = silu_f(r);
+    p.y[n] = r;
+  }
+}
+
+// fp32 -> T conversion of a flat array (n multiple of 8), e.g. the text context y[77,1024]
+struct CastParams { const float* x; void* y; long long n8; };
+template <class T>
+STAR_GLOBAL void cast_kernel(const CastParams p) {
+  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < p.n8; q += (long long)gridDim.x * blockDim.x) {
+    vec<T, 8> o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = from_f32<T>(p.x[q * 8 + e]);
+    reinterpret_cast<vec<T, 8>*>(p.y)[q] = o;
+  }
+}
+
+}  // namespace star

@@ -2,7 +2,7 @@
 // Every function enqueues on ctx->stream and returns 0 on success.
 #pragma once
 #include "ctx.h"
-#include "gemm.h"
+#include "optypes.h"
 
 namespace star {
 
@@ -18,5 +18,38 @@ struct GemmArgs {
   int force_tile = 0;  // 0 = auto; 1 = 256x256, 2 = 256x320, 3 = 128x128, 4 = 256x128 (tests)
 };
 int op_gemm(Ctx* ctx, const GemmArgs& a);
+
+}  // namespace star
+
+namespace star {
+
+struct AttnArgs {
+  const void* Q = nullptr; const void* K = nullptr; const void* V = nullptr; void* O = nullptr;
+  int ldq = 0, ldk = 0, ldv = 0, ldo = 0;
+  long long bsq = 0, bsk = 0, bsv = 0, bso = 0;
+  int Nq = 0, Nk = 0, heads = 0, batch = 0;
+  float scale = 0.125f;
+};
+int op_flash_attn(Ctx* ctx, const AttnArgs& a);
+
+struct TAttnArgs {
+  const void* Q = nullptr; const void* K = nullptr; const void* V = nullptr; void* O = nullptr;
+  int ldq = 0, ldk = 0, ldv = 0, ldo = 0;
+  int F = 0, HW = 0, heads = 0;
+  float scale = 0.125f;
+};
+int op_temporal_attn(Ctx* ctx, const TAttnArgs& a);
+
+// GroupNorm(32 groups) over channels-last rows; rows_per_stat = H*W (per frame) or F*H*W (whole chunk)
+int op_group_norm(Ctx* ctx, const void* x, int ldx, void* y, int ldy, const float* gamma, const float* beta,
+                  int rows, int C, int rows_per_stat, float eps, bool silu);
+int op_layer_norm(Ctx* ctx, const void* x, int ldx, void* y, int ldy, const float* gamma, const float* beta,
+                  int rows, int C, float eps, int mode, const float* gate_w, float* maps, int H, int W);
+int op_concat_add(Ctx* ctx, const void* a, const void* b, const void* c, void* out, int rows, int C1, int C2);
+int op_add(Ctx* ctx, const void* a, const void* b, void* out, long long n);
+int op_stem_im2col(Ctx* ctx, const float* latent, void* out, int Cl, int F, int H, int W);
+int op_rows_to_latent(Ctx* ctx, const float* rows, float* out, int Cl, int ld, long long ntok);
+int op_gemv(Ctx* ctx, const float* x, const void* W, const float* b, float* y, int N, int K, bool silu_in, bool silu_out);
+int op_cast(Ctx* ctx, const float* x, void* y, long long n);
 
 }  // namespace star

@@ -24,6 +24,28 @@ _TORCH2STAR = {torch.float16: F16, torch.bfloat16: BF16, torch.float32: F32}
 _STAR2TORCH = {v: k for k, v in _TORCH2STAR.items()}
 
 
+LN_PLAIN, LN_GATE_LINEAR, LN_GATE_MAP, LN_STATS_ONLY = 0, 1, 2, 3
+
+
+class AttnDesc(ctypes.Structure):
+    _fields_ = [
+        ("Q", ctypes.c_void_p), ("K", ctypes.c_void_p), ("V", ctypes.c_void_p), ("O", ctypes.c_void_p),
+        ("ldq", ctypes.c_int32), ("ldk", ctypes.c_int32), ("ldv", ctypes.c_int32), ("ldo", ctypes.c_int32),
+        ("bsq", ctypes.c_int64), ("bsk", ctypes.c_int64), ("bsv", ctypes.c_int64), ("bso", ctypes.c_int64),
+        ("Nq", ctypes.c_int32), ("Nk", ctypes.c_int32), ("heads", ctypes.c_int32), ("batch", ctypes.c_int32),
+        ("scale", ctypes.c_float),
+    ]
+
+
+class TAttnDesc(ctypes.Structure):
+    _fields_ = [
+        ("Q", ctypes.c_void_p), ("K", ctypes.c_void_p), ("V", ctypes.c_void_p), ("O", ctypes.c_void_p),
+        ("ldq", ctypes.c_int32), ("ldk", ctypes.c_int32), ("ldv", ctypes.c_int32), ("ldo", ctypes.c_int32),
+        ("F", ctypes.c_int32), ("HW", ctypes.c_int32), ("heads", ctypes.c_int32),
+        ("scale", ctypes.c_float),
+    ]
+
+
 class StarError(RuntimeError):
     pass
 
@@ -71,6 +93,17 @@ class Library:
         self.pool_bytes = _sig(c, "star_pool_bytes", sz, vp)
         self.pool_peak_bytes = _sig(c, "star_pool_peak_bytes", sz, vp)
         self.gemm = _sig(c, "star_gemm", i32, vp, ctypes.POINTER(GemmDesc))
+        f32 = ctypes.c_float
+        self.attn_fwd = _sig(c, "star_attn_fwd", i32, vp, ctypes.POINTER(AttnDesc))
+        self.temporal_attn_fwd = _sig(c, "star_temporal_attn_fwd", i32, vp, ctypes.POINTER(TAttnDesc))
+        self.group_norm = _sig(c, "star_group_norm", i32, vp, vp, i32, vp, i32, vp, vp, i32, i32, i32, f32, i32)
+        self.layer_norm = _sig(c, "star_layer_norm", i32, vp, vp, i32, vp, i32, vp, vp, i32, i32, f32, i32, vp, vp, i32, i32)
+        self.concat_add = _sig(c, "star_concat_add", i32, vp, vp, vp, vp, vp, i32, i32, i32)
+        self.add = _sig(c, "star_add", i32, vp, vp, vp, vp, i64)
+        self.stem_im2col = _sig(c, "star_stem_im2col", i32, vp, vp, vp, i32, i32, i32, i32)
+        self.rows_to_latent = _sig(c, "star_rows_to_latent", i32, vp, vp, vp, i32, i32, i64)
+        self.gemv = _sig(c, "star_gemv", i32, vp, vp, vp, vp, vp, i32, i32, i32, i32)
+        self.cast = _sig(c, "star_cast", i32, vp, vp, vp, i64)
 
 
 _default_library = None
@@ -176,3 +209,103 @@ class Context:
         d.force_tile = force_tile
         self._check(self.lib.gemm(self.h, ctypes.byref(d)), "gemm")
         return out
+
+    def attention(self, q, k, v, heads, out=None, scale=None):
+        """softmax(q k^T * scale) v per (batch, head).  q: [B, Nq, heads*64]; k, v: [B or 1, Nk, heads*64]
+        (a leading dim of 1 is shared by all batches).  Views with a row stride are fine (fused QKV buffers)."""
+        for t in (q, k, v):
+            self._chk_tensor(t, self.dtype)
+            assert t.dim() == 3 and t.stride(2) == 1
+        B, Nq, _ = q.shape
+        Nk = k.shape[1]
+        if out is None:
+            out = torch.empty(B, Nq, heads * 64, dtype=self.dtype, device=self.torch_device)
+        d = AttnDesc()
+        d.Q, d.K, d.V, d.O = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr()
+        d.ldq, d.ldk, d.ldv, d.ldo = q.stride(1), k.stride(1), v.stride(1), out.stride(1)
+        d.bsq, d.bso = q.stride(0), out.stride(0)
+        d.bsk = k.stride(0) if k.shape[0] > 1 else 0
+        d.bsv = v.stride(0) if v.shape[0] > 1 else 0
+        d.Nq, d.Nk, d.heads, d.batch = Nq, Nk, heads, B
+        d.scale = float(scale if scale is not None else 64 ** -0.5)
+        self._check(self.lib.attn_fwd(self.h, ctypes.byref(d)), "attn_fwd")
+        return out
+
+    def temporal_attention(self, q, k, v, F_, HW, heads, out=None, scale=None):
+        """attention over the frame axis for every (pixel, head); q/k/v: [F*HW, >=heads*64] token matrices."""
+        for t in (q, k, v):
+            self._chk_tensor(t, self.dtype)
+            assert t.dim() == 2 and t.stride(1) == 1
+        if out is None:
+            out = torch.empty(F_ * HW, heads * 64, dtype=self.dtype, device=self.torch_device)
+        d = TAttnDesc()
+        d.Q, d.K, d.V, d.O = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr()
+        d.ldq, d.ldk, d.ldv, d.ldo = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
+        d.F, d.HW, d.heads = F_, HW, heads
+        d.scale = float(scale if scale is not None else 64 ** -0.5)
+        self._check(self.lib.temporal_attn_fwd(self.h, ctypes.byref(d)), "temporal_attn_fwd")
+        return out
+
+    def group_norm(self, x, gamma, beta, rows_per_stat, eps=1e-5, silu=False, out=None):
+        """GroupNorm(32) over channels-last rows x: [rows, C]."""
+        self._chk_tensor(x, self.dtype); self._chk_tensor(gamma, torch.float32); self._chk_tensor(beta, torch.float32)
+        rows, C = x.shape
+        if out is None:
+            out = torch.empty(rows, C, dtype=self.dtype, device=self.torch_device)
+        self._check(self.lib.group_norm(self.h, _ptr(x), x.stride(0), _ptr(out), out.stride(0), _ptr(gamma), _ptr(beta),
+                                        rows, C, rows_per_stat, float(eps), int(silu)), "group_norm")
+        return out
+
+    def layer_norm(self, x, gamma, beta, eps=1e-5, mode=LN_PLAIN, gate_w=None, maps=None, H=0, W=0, out=None):
+        self._chk_tensor(x, self.dtype)
+        rows, C = x.shape
+        if mode == LN_STATS_ONLY:
+            if maps is None:
+                maps = torch.empty(rows, 2, dtype=torch.float32, device=self.torch_device)
+            self._check(self.lib.layer_norm(self.h, _ptr(x), x.stride(0), None, 8, None, None, rows, C, float(eps), mode,
+                                            None, _ptr(maps), H, W), "layer_norm")
+            return maps
+        if out is None:
+            out = torch.empty(rows, C, dtype=self.dtype, device=self.torch_device)
+        self._check(self.lib.layer_norm(self.h, _ptr(x), x.stride(0), _ptr(out), out.stride(0), _ptr(gamma), _ptr(beta),
+                                        rows, C, float(eps), mode, _ptr(gate_w), _ptr(maps), H, W), "layer_norm")
+        return out
+
+    def concat_add(self, a, b, c=None):
+        rows, C1 = a.shape
+        C2 = b.shape[1]
+        out = torch.empty(rows, C1 + C2, dtype=self.dtype, device=self.torch_device)
+        self._check(self.lib.concat_add(self.h, _ptr(a), _ptr(b), _ptr(c), _ptr(out), rows, C1, C2), "concat_add")
+        return out
+
+    def add(self, a, b):
+        out = torch.empty_like(a)
+        self._check(self.lib.add(self.h, _ptr(a), _ptr(b), _ptr(out), a.numel()), "add")
+        return out
+
+    def stem_im2col(self, latent):
+        """latent [1, Cl, F, H, W] fp32 -> [F*H*W, 64] im2col rows of the 3x3 stem conv."""
+        self._chk_tensor(latent, torch.float32)
+        _, Cl, F_, H, W = latent.shape
+        out = torch.empty(F_ * H * W, 64, dtype=self.dtype, device=self.torch_device)
+        self._check(self.lib.stem_im2col(self.h, _ptr(latent.contiguous()), _ptr(out), Cl, F_, H, W), "stem_im2col")
+        return out
+
+    def rows_to_latent(self, rows, Cl, F_, H, W):
+        self._chk_tensor(rows, torch.float32)
+        out = torch.empty(1, Cl, F_, H, W, dtype=torch.float32, device=self.torch_device)
+        self._check(self.lib.rows_to_latent(self.h, _ptr(rows), _ptr(out), Cl, rows.stride(0), F_ * H * W), "rows_to_latent")
+        return out
+
+    def gemv(self, x, W, b=None, silu_in=False, silu_out=False):
+        self._chk_tensor(x, torch.float32); self._chk_tensor(W, self.dtype)
+        N, K = W.shape
+        y = torch.empty(N, dtype=torch.float32, device=self.torch_device)
+        self._check(self.lib.gemv(self.h, _ptr(x), _ptr(W), _ptr(b), _ptr(y), N, K, int(silu_in), int(silu_out)), "gemv")
+        return y
+
+    def cast(self, x):
+        self._chk_tensor(x, torch.float32)
+        y = torch.empty(x.shape, dtype=self.dtype, device=self.torch_device)
+        self._check(self.lib.cast(self.h, _ptr(x.contiguous()), _ptr(y), x.numel()), "cast")
+        return y

@@ -1,0 +1,278 @@
+"""Unit parity of every HIP kernel family against a plain fp32 torch statement of the same op.
+
+backend "emu": the SIMT-emulator build of the same kernel sources (index logic, runs without a GPU);
+backend "hip": the real gfx950 library on a MI355X (-m gpu).  Both go through the C ABI.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from star_amd import lib as L
+from util import BACKENDS, DTYPES, assert_close, make_ctx
+
+
+@pytest.fixture(params=BACKENDS)
+def backend(request):
+    return request.param
+
+
+@pytest.fixture(params=DTYPES)
+def dtype(request):
+    return request.param
+
+
+@pytest.fixture
+def ctx(backend, dtype, request):
+    emu = request.getfixturevalue("emu_lib") if backend == "emu" else None
+    c = make_ctx(backend, dtype, emu)
+    yield c
+    c.sync()
+    c.close()
+
+
+def dev(ctx, t):
+    return t.to(ctx.torch_device)
+
+
+def nhwc_rows(x):  # [N, C, H, W] -> [N*H*W, C]
+    return x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]).contiguous()
+
+
+GEMM_CASES = [  # M, N, K, tile
+    (300, 192, 128, 3), (256, 256, 64, 1), (515, 320, 128, 2), (260, 128, 64, 4), (100, 72, 64, 0),
+    (77, 1280, 1024, 0), (1, 64, 64, 0), (600, 960, 320, 0), (513, 640, 192, 0),
+]
+
+
+@pytest.mark.parametrize("M,N,K,tile", GEMM_CASES)
+def test_gemm_bias_residual(ctx, dtype, M, N, K, tile):
+    g = torch.Generator().manual_seed(M * 7 + N)
+    A = torch.randn(M, K, generator=g).to(dtype)
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dtype)
+    b = torch.randn(N, generator=g)
+    R = torch.randn(M, N, generator=g).to(dtype)
+    out = ctx.gemm(dev(ctx, A), dev(ctx, W), bias=dev(ctx, b), res=dev(ctx, R), force_tile=tile)
+    ref = A.float() @ W.float().T + b + R.float()
+    assert_close(out, ref, dtype, what="gemm")
+    out32 = ctx.gemm(dev(ctx, A), dev(ctx, W), out_f32=True, force_tile=tile)
+    assert out32.dtype == torch.float32
+    assert_close(out32, A.float() @ W.float().T, dtype, what="gemm f32 out")
+
+
+def test_gemm_strided_views(ctx, dtype):
+    """A and the output may be column slices of wider buffers (fused QKV, concat targets)."""
+    g = torch.Generator().manual_seed(3)
+    big = torch.randn(200, 256, generator=g).to(dtype)
+    W = (torch.randn(64, 128, generator=g) * 0.1).to(dtype)
+    bigd = dev(ctx, big)
+    outbuf = torch.zeros(200, 192, dtype=dtype, device=ctx.torch_device)
+    ctx.gemm(bigd[:, 64:192], dev(ctx, W), out=outbuf[:, 64:128])
+    ref = big[:, 64:192].float() @ W.float().T
+    assert_close(outbuf[:, 64:128], ref, dtype, what="gemm strided")
+    assert float(outbuf[:, :64].abs().max()) == 0 and float(outbuf[:, 128:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("M,K,Nh", [(70, 64, 128), (300, 320, 1280)])
+def test_gemm_geglu(ctx, dtype, M, K, Nh):
+    """GEGLU epilogue (unet_v2v.py:496-504) with value/gate weight rows interleaved in 32-row blocks."""
+    from star_amd.weights import geglu_interleave
+    g = torch.Generator().manual_seed(5)
+    A = torch.randn(M, K, generator=g).to(dtype)
+    Wg = (torch.randn(2 * Nh, K, generator=g) / math.sqrt(K)).to(dtype)
+    bg = torch.randn(2 * Nh, generator=g)
+    proj = A.float() @ Wg.float().T + bg
+    ref = proj[:, :Nh] * F.gelu(proj[:, Nh:])
+    idx = geglu_interleave(Nh)
+    out = ctx.gemm(dev(ctx, A), dev(ctx, Wg[idx].contiguous()), bias=dev(ctx, bg[idx].contiguous()), geglu=True)
+    assert_close(out, ref, dtype, what="geglu")
+
+
+CONV_CASES = [  # NB, Cin, H, W, Cout
+    (2, 64, 10, 8, 96), (1, 128, 18, 16, 64), (3, 320, 10, 8, 320),
+]
+
+
+@pytest.mark.parametrize("NB,Cin,H,Wd,Cout", CONV_CASES)
+def test_conv3x3_variants(ctx, dtype, NB, Cin, H, Wd, Cout):
+    g = torch.Generator().manual_seed(Cin + H)
+    x = torch.randn(NB, Cin, H, Wd, generator=g).to(dtype)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)).to(dtype)
+    b = torch.randn(Cout, generator=g)
+    wp = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous()
+    xr, wpd, bd = dev(ctx, nhwc_rows(x)), dev(ctx, wp), dev(ctx, b)
+    # ResBlock / Upsample conv: 3x3 stride 1 pad 1 (unet_v2v.py:612,639)
+    ref = F.conv2d(x.float(), w.float(), b, padding=1)
+    out = ctx.gemm(xr, wpd, bias=bd, mode=L.A_CONV3X3, conv=(NB, H, Wd, Cin, H, Wd, 1, 1, 1))
+    assert_close(out, nhwc_rows(ref), dtype, what="conv3x3 s1")
+    # Downsample: stride 2, padding (2, 1) (unet_v2v.py:709-722)
+    ref = F.conv2d(x.float(), w.float(), b, stride=2, padding=(2, 1))
+    Ho, Wo = ref.shape[2:]
+    assert Ho == H // 2 + 1 and Wo == Wd // 2
+    out = ctx.gemm(xr, wpd, bias=bd, mode=L.A_CONV3X3, conv=(NB, H, Wd, Cin, Ho, Wo, 2, 2, 1))
+    assert_close(out, nhwc_rows(ref), dtype, what="conv3x3 s2")
+    # Upsample: nearest x2, drop first/last row, conv (unet_v2v.py:563-566)
+    xu = F.interpolate(x.float(), scale_factor=2, mode="nearest")[..., 1:-1, :]
+    ref = F.conv2d(xu, w.float(), b, padding=1)
+    Ho, Wo = ref.shape[2:]
+    out = ctx.gemm(xr, wpd, bias=bd, mode=L.A_CONV3X3_UP, conv=(NB, H, Wd, Cin, Ho, Wo, 1, 1, 1))
+    assert_close(out, nhwc_rows(ref), dtype, what="conv3x3 up")
+
+
+@pytest.mark.parametrize("Fr,H,Wd,C", [(5, 3, 4, 64), (8, 6, 8, 128), (1, 4, 4, 64)])
+def test_temporal_conv(ctx, dtype, Fr, H, Wd, C):
+    """Conv3d (3,1,1) pad (1,0,0) + identity (TemporalConvBlock_v2, unet_v2v.py:1209-1220,1277)."""
+    g = torch.Generator().manual_seed(Fr)
+    x = torch.randn(1, C, Fr, H, Wd, generator=g).to(dtype)
+    w = (torch.randn(C, C, 3, 1, 1, generator=g) / math.sqrt(3 * C)).to(dtype)
+    b = torch.randn(C, generator=g)
+    res = torch.randn(Fr * H * Wd, C, generator=g).to(dtype)
+    ref = F.conv3d(x.float(), w.float(), b, padding=(1, 0, 0))[0].permute(1, 2, 3, 0).reshape(-1, C) + res.float()
+    a = x[0].permute(1, 2, 3, 0).reshape(-1, C).contiguous()
+    wp = w[:, :, :, 0, 0].permute(0, 2, 1).reshape(C, 3 * C).contiguous()
+    out = ctx.gemm(dev(ctx, a), dev(ctx, wp), bias=dev(ctx, b), res=dev(ctx, res), mode=L.A_TCONV3, temporal=(Fr, H * Wd, C))
+    assert_close(out, ref, dtype, what="tconv")
+
+
+def ref_attention(q, k, v, heads):
+    B = q.shape[0]
+    sp = lambda t: t.float().reshape(t.shape[0], -1, heads, 64).transpose(1, 2)
+    o = F.scaled_dot_product_attention(sp(q), sp(k).expand(B, -1, -1, -1), sp(v).expand(B, -1, -1, -1))
+    return o.transpose(1, 2).reshape(B, -1, heads * 64)
+
+
+@pytest.mark.parametrize("B,heads,Nq,Nk", [(2, 2, 300, 300), (1, 5, 80, 80), (3, 1, 257, 64), (1, 2, 64, 1), (9, 1, 33, 130)])
+def test_flash_attention_self(ctx, dtype, B, heads, Nq, Nk):
+    """spatial self-attention (unet_v2v.py:472 -> :184) on a fused QKV buffer, ragged q/k tails."""
+    g = torch.Generator().manual_seed(Nq + Nk)
+    C = heads * 64
+    N = max(Nq, Nk)
+    qkv = torch.randn(B, N, 3 * C, generator=g).to(dtype)
+    q, k, v = qkv[:, :Nq, :C], qkv[:, :Nk, C:2 * C], qkv[:, :Nk, 2 * C:]
+    qkvd = dev(ctx, qkv)
+    out = ctx.attention(qkvd[:, :Nq, :C], qkvd[:, :Nk, C:2 * C], qkvd[:, :Nk, 2 * C:], heads)
+    assert_close(out, ref_attention(q, k, v, heads), dtype, what="flash self")
+
+
+def test_flash_attention_cross_77(ctx, dtype):
+    """cross-attention to the 77 text tokens, K/V shared by all frames (unet_v2v.py:476)."""
+    g = torch.Generator().manual_seed(77)
+    B, heads, Nq = 3, 2, 200
+    q = torch.randn(B, Nq, 128, generator=g).to(dtype)
+    kv = torch.randn(1, 77, 256, generator=g).to(dtype)
+    kvd = dev(ctx, kv)
+    out = ctx.attention(dev(ctx, q), kvd[..., :128], kvd[..., 128:], heads)
+    assert_close(out, ref_attention(q, kv[..., :128], kv[..., 128:], heads), dtype, what="flash cross")
+
+
+def test_flash_attention_forced_rescale(ctx, dtype):
+    """a key spike late in the sequence forces the online-softmax rescale branch with a large max jump."""
+    g = torch.Generator().manual_seed(11)
+    B, heads, N = 1, 1, 400
+    q = torch.randn(B, N, 64, generator=g)
+    k = torch.randn(B, N, 64, generator=g)
+    v = torch.randn(B, N, 64, generator=g)
+    k[:, 333] = q[:, 7] * 4.0     # q.k ~ 4*64 = 256 against O(8) elsewhere
+    k[:, 2] = q[:, 100] * 3.0     # and an early spike that later tiles must not disturb
+    q, k, v = q.to(dtype), k.to(dtype), v.to(dtype)
+    out = ctx.attention(dev(ctx, q), dev(ctx, k), dev(ctx, v), heads)
+    assert_close(out, ref_attention(q, k, v, heads), dtype, what="flash rescale")
+
+
+@pytest.mark.parametrize("Fr,HW,heads", [(5, 7, 2), (32, 9, 1), (40, 5, 2), (16, 130, 5), (1, 4, 1)])
+def test_temporal_attention(ctx, dtype, Fr, HW, heads):
+    """attention over frames per pixel (unet_v2v.py:483-489), tokens stay in [F*HW, C] order."""
+    g = torch.Generator().manual_seed(Fr * 31 + HW)
+    C = heads * 64
+    qkv = torch.randn(Fr * HW, 3 * C, generator=g).to(dtype)
+    qkvd = dev(ctx, qkv)
+    out = ctx.temporal_attention(qkvd[:, :C], qkvd[:, C:2 * C], qkvd[:, 2 * C:], Fr, HW, heads)
+    tr = lambda x: x.float().reshape(Fr, HW, heads, 64).permute(1, 2, 0, 3)
+    ref = F.scaled_dot_product_attention(tr(qkv[:, :C]), tr(qkv[:, C:2 * C]), tr(qkv[:, 2 * C:]))
+    ref = ref.permute(2, 0, 1, 3).reshape(Fr * HW, C)
+    assert_close(out, ref, dtype, what="temporal attn")
+
+
+@pytest.mark.parametrize("C", [320, 128, 2560, 960, 512, 1920])
+@pytest.mark.parametrize("silu", [False, True])
+def test_group_norm(ctx, dtype, C, silu):
+    """GroupNorm(32): per-frame statistics (4-D call sites) and whole-chunk statistics (5-D call sites)."""
+    g = torch.Generator().manual_seed(C)
+    NF, HW = 3, 50
+    x = (torch.randn(NF * HW, C, generator=g) * 2 + 0.5).to(dtype)
+    gam, bet = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    for rps, eps in ((HW, 1e-5), (NF * HW, 1e-6)):
+        out = ctx.group_norm(dev(ctx, x), dev(ctx, gam), dev(ctx, bet), rps, eps=eps, silu=silu)
+        xr = x.float().reshape(-1, rps, C).permute(0, 2, 1)
+        ref = F.group_norm(xr, 32, gam, bet, eps)
+        if silu:
+            ref = F.silu(ref)
+        assert_close(out, ref.permute(0, 2, 1).reshape(-1, C), dtype, what=f"gn rps={rps}")
+
+
+def test_group_norm_large_mean(ctx, dtype):
+    """fp64 sum / sum-of-squares accumulation must survive |mean| >> std."""
+    g = torch.Generator().manual_seed(9)
+    C, rows = 64, 4096
+    x = (torch.randn(rows, C, generator=g) * 0.05 + 6.0).to(dtype)
+    gam, bet = torch.ones(C), torch.zeros(C)
+    out = ctx.group_norm(dev(ctx, x), dev(ctx, gam), dev(ctx, bet), rows, eps=1e-5)
+    ref = F.group_norm(x.float().t().unsqueeze(0), 32, gam, bet, 1e-5)[0].t()
+    assert_close(out, ref, dtype, scale=8.0, what="gn large mean")
+
+
+@pytest.mark.parametrize("C", [320, 512, 640, 1280, 2560])
+def test_layer_norm_and_liem_gates(ctx, dtype, C):
+    g = torch.Generator().manual_seed(C + 1)
+    Fr, H, W = 2, 6, 5
+    rows = Fr * H * W
+    x = torch.randn(rows, C, generator=g).to(dtype)
+    gam, bet = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    xd, gd, bd = dev(ctx, x), dev(ctx, gam), dev(ctx, bet)
+    xf = x.float()
+    assert_close(ctx.layer_norm(xd, gd, bd), F.layer_norm(xf, (C,), gam, bet), dtype, what="ln")
+    # TemporalLocalAttention (unet_v2v.py:396-411): sigmoid(Linear(2,1)([max_c, mean_c])) * x
+    w2 = torch.randn(2, generator=g)
+    gate = torch.sigmoid(w2[0] * xf.max(-1, keepdim=True)[0] + w2[1] * xf.mean(-1, keepdim=True))
+    out = ctx.layer_norm(xd, gd, bd, mode=L.LN_GATE_LINEAR, gate_w=dev(ctx, w2))
+    assert_close(out, F.layer_norm(gate * xf, (C,), gam, bet), dtype, what="ln temporal gate")
+    # SpatialAttention (unet_v2v.py:380-394): sigmoid(conv7x7([max_c, mean_c])) * x
+    w7 = torch.randn(1, 2, 7, 7, generator=g) * 0.3
+    maps = ctx.layer_norm(xd, None, None, mode=L.LN_STATS_ONLY)
+    out = ctx.layer_norm(xd, gd, bd, mode=L.LN_GATE_MAP, gate_w=dev(ctx, w7.reshape(-1).contiguous()), maps=maps, H=H, W=W)
+    xi = xf.reshape(Fr, H, W, C).permute(0, 3, 1, 2)
+    wmap = torch.cat([xi.max(1, keepdim=True)[0], xi.mean(1, keepdim=True)], 1)
+    gate = torch.sigmoid(F.conv2d(wmap, w7, padding=3))
+    ref = F.layer_norm((gate * xi).permute(0, 2, 3, 1).reshape(rows, C), (C,), gam, bet)
+    assert_close(out, ref, dtype, what="ln spatial gate")
+
+
+def test_plumbing_kernels(ctx, dtype):
+    g = torch.Generator().manual_seed(2)
+    a = torch.randn(40, 64, generator=g).to(dtype)
+    b = torch.randn(40, 32, generator=g).to(dtype)
+    c = torch.randn(40, 32, generator=g).to(dtype)
+    out = ctx.concat_add(dev(ctx, a), dev(ctx, b), dev(ctx, c))
+    assert_close(out, torch.cat([a.float(), b.float() + c.float()], 1), dtype, what="concat_add")
+    out = ctx.concat_add(dev(ctx, a), dev(ctx, b))
+    assert_close(out, torch.cat([a.float(), b.float()], 1), dtype, what="concat")
+    assert_close(ctx.add(dev(ctx, a), dev(ctx, a)), 2 * a.float(), dtype, what="add")
+    # stem conv 4 -> 320 through im2col rows (unet_v2v.py:1353)
+    lat = torch.randn(1, 4, 3, 6, 8, generator=g)
+    w = torch.randn(320, 4, 3, 3, generator=g) * 0.2
+    cols = ctx.stem_im2col(dev(ctx, lat))
+    wp = torch.zeros(320, 64)
+    wp[:, :36] = w.permute(0, 2, 3, 1).reshape(320, 36)
+    o = ctx.gemm(cols, dev(ctx, wp.to(dtype)), out_f32=True)
+    ref = F.conv2d(lat[0].permute(1, 0, 2, 3).to(dtype).float(), w.to(dtype).float(), padding=1).permute(0, 2, 3, 1).reshape(-1, 320)
+    assert_close(o, ref, dtype, what="stem conv")
+    r2l = ctx.rows_to_latent(o[:, :8].contiguous(), 4, 3, 6, 8)
+    assert torch.equal(r2l[0].cpu(), o[:, :4].reshape(3, 6, 8, 4).permute(3, 0, 1, 2).cpu())
+    xv = torch.randn(320, generator=g)
+    Wv = (torch.randn(1280, 320, generator=g) * 0.1).to(dtype)
+    bv = torch.randn(1280, generator=g)
+    y = ctx.gemv(dev(ctx, xv), dev(ctx, Wv), dev(ctx, bv), silu_in=True, silu_out=True)
+    ref = F.silu(F.silu(xv) @ Wv.float().T + bv)
+    assert float((y.cpu() - ref).abs().max()) < 1e-4
+    assert torch.equal(ctx.cast(dev(ctx, xv)).cpu(), xv.to(dtype))
