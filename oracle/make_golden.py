@@ -1,0 +1,214 @@
+"""Generate tests/golden/* by executing the REFERENCE's own code on CPU (this container only).
+
+    python oracle/make_golden.py [--full]
+
+Fixtures (all seeded, regenerable):
+  unet_state_dict_shapes.json   {key: shape} of ControlledV2VUNet().state_dict()  (meta device)
+  unet_small_*.pt               reference forward of a reduced-width ControlledV2VUNet (dim 64) on several
+                                legal latent shapes: inputs are re-derived from seeds, only the output is stored
+  unet_full_f2_10x8.pt          (--full) the full 2.04 B-parameter model on a tiny latent
+  blocks_*.pt                   reference ResBlock / SpatialTransformer / TemporalTransformer / Up / Down outputs
+  sampler_*.pt                  sigma ladders, schedule values, pad_to_fit / make_chunks tables, a sample_sr
+                                trajectory with a toy denoiser and an injected noise source
+"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import ref_loader  # noqa: E402
+from star_amd.topology import SMALL_TEST_CONFIG, UNetConfig, random_state_dict  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def unet_inputs(cfg, f, h, w, seed):
+    """The synthetic inputs shared by golden generation and the parity tests."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(1, 4, f, h, w, generator=g)
+    hint = torch.randn(1, 4, f, h, w, generator=g) * 0.5
+    y = torch.randn(1, 77, cfg.context_dim, generator=g)
+    t = torch.tensor([int(torch.randint(0, 1000, (1,), generator=g))], dtype=torch.long)
+    return x, t, y, hint
+
+
+def build_reference_unet(cfg):
+    m = ref_loader.load_unet_module()
+    kw = dict(in_dim=cfg.in_dim, dim=cfg.dim, y_dim=cfg.context_dim, context_dim=cfg.context_dim, out_dim=cfg.out_dim,
+              dim_mult=list(cfg.dim_mult), num_heads=cfg.num_heads, head_dim=cfg.head_dim,
+              num_res_blocks=cfg.num_res_blocks, attn_scales=list(cfg.attn_scales))
+
+    class Ctl(m.ControlledV2VUNet):   # ControlledV2VUNet.__init__ takes no arguments (unet_v2v.py:1713-1715)
+        def __init__(self):
+            m.Vid2VidSDUNet.__init__(self, **kw)
+            self.VideoControlNet = m.VideoControlNet(**kw)
+            # the reference hard-codes add_dim = 320 (unet_v2v.py:2125-2128), which equals dim only at full width;
+            # for the reduced-width fixture the hint conv must produce `dim` channels to be addable to x (:2193)
+            if cfg.dim != 320:
+                self.VideoControlNet.input_hint_block = m.zero_module(torch.nn.Conv2d(4, cfg.dim, 3, padding=1))
+
+    net = Ctl() if cfg != UNetConfig() else m.ControlledV2VUNet()
+    return net.eval()
+
+
+SMALL_CASES = [(4, 10, 8, 101), (3, 18, 16, 102), (8, 10, 16, 103), (33, 10, 8, 104), (1, 10, 8, 105)]
+
+
+def gen_unet(cfg, cases, tag, wseed=0):
+    net = build_reference_unet(cfg)
+    sd = random_state_dict(cfg, seed=wseed)
+    missing = net.load_state_dict(sd, strict=True)
+    print(tag, "loaded", missing)
+    for (f, h, w, seed) in cases:
+        x, t, y, hint = unet_inputs(cfg, f, h, w, seed)
+        with torch.no_grad():
+            out = net(x, t=t, y=y, hint=hint)
+        path = os.path.join(GOLD, f"unet_{tag}_f{f}_{h}x{w}.pt")
+        torch.save({"out": out.clone(), "case": (f, h, w, seed), "wseed": wseed}, path)
+        print("wrote", path, tuple(out.shape), float(out.abs().mean()))
+
+
+def gen_shapes():
+    m = ref_loader.load_unet_module()
+    with torch.device("meta"):
+        net = m.ControlledV2VUNet()
+    shapes = {k: list(v.shape) for k, v in net.state_dict().items()}
+    json.dump(shapes, open(os.path.join(GOLD, "unet_state_dict_shapes.json"), "w"), indent=0)
+
+
+def gen_sampler():
+    dif, sol, sch = ref_loader.load_diffusion_modules()
+    sig = sch.noise_schedule(schedule="logsnr_cosine_interp", n=1000, zero_terminal_snr=True, scale_min=2.0, scale_max=4.0)
+    gd = dif.GaussianDiffusion(sigmas=sig)
+    out = {"sigmas": sig.clone(), "alphas": gd.alphas.clone()}
+    # sigma ladders handed to the solver: capture them by stubbing the solver function
+    captured = {}
+
+    def fake_solver(noise, fn, sigmas, **kw):
+        captured["sigmas"] = sigmas.clone()
+        return noise
+
+    for mode, steps in (("fast", 15), ("normal", 50), ("normal", 5), ("normal", 7)):
+        orig = dif.sample_dpmpp_2m_sde
+        dif.sample_dpmpp_2m_sde = fake_solver
+        try:
+            gd.sample_sr(noise=torch.zeros(1, 4, 2, 2, 2), model=None, model_kwargs=[{}, {}, {}], guide_scale=7.5,
+                         guide_rescale=0.2, solver="dpmpp_2m_sde", solver_mode=mode, steps=steps, t_max=899, t_min=0,
+                         discretization="trailing", chunk_inds=None)
+        finally:
+            dif.sample_dpmpp_2m_sde = orig
+        s = captured["sigmas"]
+        ts = torch.stack([gd._sigma_to_t(x).round().long()[0] for x in s[:-1]])
+        out[f"ladder_{mode}_{steps}"] = {"sigmas": s, "t": ts}
+    # geometry helpers live in video_to_video_model.py which imports diffusers/open_clip; execute just the functions
+    src = open(os.path.join(ref_loader.REF_ROOT, "video_to_video/video_to_video_model.py")).read()
+    start = src.index("def pad_to_fit")
+    ns = {}
+    exec(compile(src[start:], "ref_geometry", "exec"), ns)
+    out["pad_to_fit"] = {(h, w): ns["pad_to_fit"](h, w) for (h, w) in
+                         [(512, 512), (960, 1704), (2160, 3840), (720, 1280), (480, 720), (1000, 1300), (720, 1300), (100, 2000)]}
+    out["make_chunks"] = {(f, mx): ns["make_chunks"](f, 0, mx) for (f, mx) in
+                          [(72, 32), (72, 16), (64, 32), (41, 32), (33, 32), (40, 32), (100, 32), (17, 16), (48, 24)]}
+    # denoise(): CFG + rescale + v->x0 with a toy linear "model"
+    g = torch.Generator().manual_seed(5)
+    xt = torch.randn(1, 4, 6, 10, 8, generator=g)
+    A = torch.randn(4, 4, generator=g) * 0.3
+
+    def toy_model(x, t, y=None, hint=None, hint_chunk=None, variant_info=None):
+        h_ = hint_chunk if hint_chunk is not None else hint
+        return torch.einsum("oc,bcfhw->bofhw", A, x) * (1.0 + 0.1 * float(y.mean())) + 0.05 * h_ + 0.001 * float(t[0])
+
+    y1, y2 = torch.randn(1, 77, 16, generator=g), torch.randn(1, 77, 16, generator=g)
+    hint = torch.randn(1, 4, 6, 10, 8, generator=g)
+    t = torch.tensor([749])
+    x0 = gd.denoise(xt, t, None, toy_model, [{"y": y1}, {"y": y2}, {"hint": hint}], 7.5, 0.2)[-2]
+    out["denoise"] = {"xt": xt, "A": A, "y1": y1, "y2": y2, "hint": hint, "t": t, "x0": x0}
+    # full sample_sr trajectory with chunking and an injected noise source (torchsde is absent: the Brownian
+    # tree is replaced by seeded per-step randn)
+    class InjectedNoise:
+        def __init__(self, x, smin, smax, seed=None, transform=None):
+            self.g = torch.Generator().manual_seed(1234)
+            self.shape = x.shape
+
+        def __call__(self, s, s_next):
+            return torch.randn(self.shape, generator=self.g)
+
+    sol.BrownianTreeNoiseSampler = InjectedNoise
+    for name, frames, chunks, mode, steps in (("nochunk", 6, None, "normal", 5), ("chunked", 41, ns["make_chunks"](41, 0, 32), "fast", 15),
+                                              ("chunked3", 72, ns["make_chunks"](72, 0, 32), "normal", 4)):
+        g = torch.Generator().manual_seed(77)
+        noise = torch.randn(1, 4, frames, 10, 8, generator=g)
+        hint = torch.randn(1, 4, frames, 10, 8, generator=g)
+        res = gd.sample_sr(noise=noise, model=toy_model, model_kwargs=[{"y": y1}, {"y": y2}, {"hint": hint}], guide_scale=7.5,
+                           guide_rescale=0.2, solver="dpmpp_2m_sde", solver_mode=mode, steps=steps, t_max=899, t_min=0,
+                           discretization="trailing", chunk_inds=chunks)
+        out[f"sample_{name}"] = {"noise": noise, "hint": hint, "chunks": chunks, "mode": mode, "steps": steps, "x0": res}
+    torch.save(out, os.path.join(GOLD, "sampler.pt"))
+    print("wrote sampler.pt", list(out.keys()))
+
+
+def gen_blocks():
+    """Outputs of individual reference modules with their own default (seeded) init + randomised zero-inits."""
+    m = ref_loader.load_unet_module()
+    out = {}
+    torch.manual_seed(11)
+    cases = {
+        "res_64_128": (lambda: m.ResBlock(64, 256, 0.1, out_channels=128, use_scale_shift_norm=False), "res"),
+        "res_128_128": (lambda: m.ResBlock(128, 256, 0.1, out_channels=128, use_scale_shift_norm=False), "res"),
+        "st_128": (lambda: m.SpatialTransformer(128, 2, 64, depth=1, context_dim=96, disable_self_attn=False, use_linear=True, is_ctrl=True), "st"),
+        "tt_64_128": (lambda: m.TemporalTransformer(64, 2, 64, depth=1, context_dim=96, disable_self_attn=False, use_linear=False, multiply_zero=False, is_ctrl=True), "tt"),
+        "down_64": (lambda: m.Downsample(64, True, dims=2, out_channels=64), "down"),
+        "up_64": (lambda: m.Upsample(64, True, dims=2.0, out_channels=64), "up"),
+    }
+    for name, (ctor, kind) in cases.items():
+        mod = ctor().eval()
+        ref_loader.randomize_zero_init(mod, seed=3)
+        g = torch.Generator().manual_seed(21)
+        f, h, w = 3, 10, 8
+        cin = {"res_64_128": 64, "res_128_128": 128, "st_128": 128, "tt_64_128": 64, "down_64": 64, "up_64": 64}[name]
+        x = torch.randn(f, cin, h, w, generator=g)
+        with torch.no_grad():
+            if kind == "res":
+                emb = torch.randn(1, 256, generator=g).repeat_interleave(f, dim=0)
+                y = mod(x, emb, 1, None)
+                extra = {"emb": emb}
+            elif kind == "st":
+                ctx = torch.randn(1, 77, 96, generator=g).repeat_interleave(f, dim=0)
+                y = mod(x, ctx)
+                extra = {"context": ctx}
+            elif kind == "tt":
+                x5 = x.reshape(1, f, cin, h, w).permute(0, 2, 1, 3, 4)
+                y = mod(x5, None).permute(0, 2, 1, 3, 4).reshape(f, cin, h, w)
+                extra = {}
+            else:
+                y = mod(x)
+                extra = {}
+        out[name] = {"sd": {k: v.clone() for k, v in mod.state_dict().items()}, "x": x, "y": y, "kind": kind, **extra}
+        print(name, tuple(y.shape))
+    torch.save(out, os.path.join(GOLD, "blocks.pt"))
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--full", action="store_true")
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    assert ref_loader.reference_available(), "needs /root/reference"
+    os.makedirs(GOLD, exist_ok=True)
+    torch.set_grad_enabled(False)
+    only = set(a.only.split(",")) if a.only else None
+    if only is None or "shapes" in only:
+        gen_shapes()
+    if only is None or "sampler" in only:
+        gen_sampler()
+    if only is None or "blocks" in only:
+        gen_blocks()
+    if only is None or "small" in only:
+        gen_unet(SMALL_TEST_CONFIG, SMALL_CASES, "small")
+    if a.full:
+        gen_unet(UNetConfig(), [(2, 10, 8, 201)], "full")
