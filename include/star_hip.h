@@ -96,6 +96,28 @@ int star_rows_to_latent(star_ctx* ctx, const float* rows, float* out, int32_t Cl
 int star_gemv(star_ctx* ctx, const float* x, const void* W, const float* b, float* y, int32_t N, int32_t K, int32_t silu_in, int32_t silu_out);
 int star_cast(star_ctx* ctx, const float* x, void* y, int64_t n);
 
+/* ---- weights + model (B4: torch.load(...)/load_state_dict, video_to_video_model.py:36-43) ------------- */
+typedef struct star_unet_config {
+  int32_t in_dim, dim, context_dim, out_dim;
+  int32_t n_levels; int32_t dim_mult[8];
+  int32_t num_heads, head_dim, num_res_blocks, attn_levels;
+} star_unet_config;
+/* stage one tensor of the reference state dict (host pointer, reference key name, fp32/fp16/bf16) */
+int star_load_tensor(star_ctx* ctx, const char* name, const void* host_ptr, const int64_t* shape, int32_t ndim, int32_t dtype);
+/* repack the staged tensors (NHWC conv weights, fused QKV, GEGLU interleave) and upload; frees the staging copies */
+int star_unet_build(star_ctx* ctx, const star_unet_config* cfg);
+/* replaces: ControlledV2VUNet.forward(x, t, y, hint=...) -> v-prediction (B2; unet_v2v.py:1717-1809,
+ * called from GaussianDiffusion.denoise diffusion_sdedit.py:81,88).  xt, hint, out: fp32 device [1, 4, f, h, w];
+ * y: fp32 device [77, context_dim]; t: the integer timestep. */
+int star_unet_forward(star_ctx* ctx, const float* xt, int64_t t, const float* y, const float* hint, float* out,
+                      int32_t f, int32_t h, int32_t w);
+/* one reference module (ResBlock / SpatialTransformer / TemporalTransformer / Downsample / Upsample) built from
+ * staged tensors `prefix.*`; kind: 0 res, 1 spatial, 2 temporal, 3 down, 4 up.  x/out: channels-last rows (ctx dtype) */
+int star_module_run(star_ctx* ctx, int32_t kind, const char* prefix, int32_t cin, int32_t cout, int32_t heads,
+                    int32_t embed_dim, int32_t context_dim, const void* x, const float* emb, const float* context,
+                    void* out, int32_t f, int32_t h, int32_t w);
+int star_clear_staged(star_ctx* ctx);
+
 #ifdef __cplusplus
 }
 #endif

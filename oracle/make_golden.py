@@ -160,8 +160,8 @@ def gen_blocks():
     cases = {
         "res_64_128": (lambda: m.ResBlock(64, 256, 0.1, out_channels=128, use_scale_shift_norm=False), "res"),
         "res_128_128": (lambda: m.ResBlock(128, 256, 0.1, out_channels=128, use_scale_shift_norm=False), "res"),
-        "st_128": (lambda: m.SpatialTransformer(128, 2, 64, depth=1, context_dim=96, disable_self_attn=False, use_linear=True, is_ctrl=True), "st"),
-        "tt_64_128": (lambda: m.TemporalTransformer(64, 2, 64, depth=1, context_dim=96, disable_self_attn=False, use_linear=False, multiply_zero=False, is_ctrl=True), "tt"),
+        "st_128": (lambda: m.SpatialTransformer(128, 2, 64, depth=1, context_dim=128, disable_self_attn=False, use_linear=True, is_ctrl=True), "st"),
+        "tt_64_128": (lambda: m.TemporalTransformer(64, 2, 64, depth=1, context_dim=128, disable_self_attn=False, use_linear=False, multiply_zero=False, is_ctrl=True), "tt"),
         "down_64": (lambda: m.Downsample(64, True, dims=2, out_channels=64), "down"),
         "up_64": (lambda: m.Upsample(64, True, dims=2.0, out_channels=64), "up"),
     }
@@ -178,7 +178,7 @@ def gen_blocks():
                 y = mod(x, emb, 1, None)
                 extra = {"emb": emb}
             elif kind == "st":
-                ctx = torch.randn(1, 77, 96, generator=g).repeat_interleave(f, dim=0)
+                ctx = torch.randn(1, 77, 128, generator=g).repeat_interleave(f, dim=0)
                 y = mod(x, ctx)
                 extra = {"context": ctx}
             elif kind == "tt":

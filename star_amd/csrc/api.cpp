@@ -1,6 +1,8 @@
 // api.cpp -- the C ABI (include/star_hip.h) over the C++ launchers.
 #include "../../include/star_hip.h"
 #include "ops.h"
+#include "unet.h"
+#include <cstring>
 
 using namespace star;
 
@@ -102,5 +104,38 @@ int star_gemv(star_ctx* h, const float* x, const void* W, const float* b, float*
   return op_gemv(&h->c, x, W, b, y, N, K, silu_in != 0, silu_out != 0);
 }
 int star_cast(star_ctx* h, const float* x, void* y, int64_t n) { return op_cast(&h->c, x, y, n); }
+
+
+int star_load_tensor(star_ctx* h, const char* name, const void* host, const int64_t* shape, int32_t ndim, int32_t dtype) {
+  HostTensor t;
+  size_t n = 1;
+  for (int i = 0; i < ndim; ++i) { t.shape.push_back(shape[i]); n *= (size_t)shape[i]; }
+  t.data.resize(n);
+  if (dtype == DT_F32) memcpy(t.data.data(), host, n * 4);
+  else if (dtype == DT_F16) { const f16* s = (const f16*)host; for (size_t i = 0; i < n; ++i) t.data[i] = (float)s[i]; }
+  else if (dtype == DT_BF16) { const uint16_t* s = (const uint16_t*)host; for (size_t i = 0; i < n; ++i) { uint32_t u = (uint32_t)s[i] << 16; memcpy(&t.data[i], &u, 4); } }
+  else return h->c.fail("load_tensor: bad dtype");
+  h->c.host_tensors[name] = std::move(t);
+  return 0;
+}
+int star_clear_staged(star_ctx* h) { h->c.host_tensors.clear(); return 0; }
+int star_unet_build(star_ctx* h, const star_unet_config* c) {
+  UNetCfg cfg;
+  cfg.in_dim = c->in_dim; cfg.dim = c->dim; cfg.context_dim = c->context_dim; cfg.out_dim = c->out_dim;
+  cfg.n_levels = c->n_levels;
+  for (int i = 0; i < 8; ++i) cfg.dim_mult[i] = c->dim_mult[i];
+  cfg.num_heads = c->num_heads; cfg.head_dim = c->head_dim; cfg.num_res_blocks = c->num_res_blocks; cfg.attn_levels = c->attn_levels;
+  if (cfg.head_dim != 64) return h->c.fail("unet_build: head_dim must be 64");
+  if (cfg.dim % 64) return h->c.fail("unet_build: dim must be a multiple of 64");
+  if (cfg.n_levels < 1 || cfg.n_levels > 8) return h->c.fail("unet_build: bad n_levels");
+  return unet_build(&h->c, cfg);
+}
+int star_unet_forward(star_ctx* h, const float* xt, int64_t t, const float* y, const float* hint, float* out, int32_t f, int32_t hh, int32_t w) {
+  return unet_forward(&h->c, xt, (long long)t, y, hint, out, f, hh, w);
+}
+int star_module_run(star_ctx* h, int32_t kind, const char* prefix, int32_t cin, int32_t cout, int32_t heads, int32_t embed_dim,
+                    int32_t context_dim, const void* x, const float* emb, const float* context, void* out, int32_t f, int32_t hh, int32_t w) {
+  return module_run(&h->c, kind, prefix, cin, cout, heads, embed_dim, context_dim, x, emb, context, out, f, hh, w);
+}
 
 }  // extern "C"

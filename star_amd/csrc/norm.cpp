@@ -110,6 +110,12 @@ int op_gemv(Ctx* ctx, const float* x, const void* W, const float* b, float* y, i
   return 0;
 }
 
+int op_vec_add_f32(Ctx* ctx, float* a, const float* b, int n) {
+  VecAddParams p{a, b, n};
+  STAR_LAUNCH(vec_add_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), (size_t)0, ctx->stream, p);
+  return 0;
+}
+
 int op_cast(Ctx* ctx, const float* x, void* y, long long n) {
   if (n & 7) return ctx->fail("cast: n must be a multiple of 8");
   CastParams p{x, y, n / 8};

@@ -297,6 +297,13 @@ STAR_GLOBAL void gemv_kernel(const GemvParams p) {
   }
 }
 
+// a[i] += b[i] (fp32, small vectors: conv bias + time-embedding projection)
+struct VecAddParams { float* a; const float* b; int n; };
+STAR_GLOBAL void vec_add_f32_kernel(const VecAddParams p) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < p.n) p.a[i] += p.b[i];
+}
+
 // fp32 -> T conversion of a flat array (n multiple of 8), e.g. the text context y[77,1024]
 struct CastParams { const float* x; void* y; long long n8; };
 template <class T>

@@ -51,5 +51,6 @@ int op_stem_im2col(Ctx* ctx, const float* latent, void* out, int Cl, int F, int 
 int op_rows_to_latent(Ctx* ctx, const float* rows, float* out, int Cl, int ld, long long ntok);
 int op_gemv(Ctx* ctx, const float* x, const void* W, const float* b, float* y, int N, int K, bool silu_in, bool silu_out);
 int op_cast(Ctx* ctx, const float* x, void* y, long long n);
+int op_vec_add_f32(Ctx* ctx, float* a, const float* b, int n);
 
 }  // namespace star

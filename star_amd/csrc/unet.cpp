@@ -1,0 +1,648 @@
+// unet.cpp -- the ControlledV2VUNet graph executor: weight repacking and the static schedule of
+// HIP kernels for one denoiser forward (reference: ControlledV2VUNet.forward unet_v2v.py:1717-1809,
+// VideoControlNet.forward :2134-2206 and the block internals cited in ops below).
+//
+// Activations are channels-last token matrices [F*H*W, C] for the whole forward; the reference's
+// (b f) c h w <-> b c f h w <-> (b h w) f c rearranges never materialise: spatial kernels index
+// tokens by (frame, y, x), temporal kernels stride over frames by H*W rows.
+#include "unet.h"
+#include <cmath>
+#include <cstring>
+
+namespace star {
+
+UNetModel::~UNetModel() { for (void* p : owned) rt::dev_free(p); }
+
+// ------------------------------------------------------------------ weight staging / repacking
+namespace {
+
+struct Builder {
+  Ctx* ctx;
+  std::vector<void*>* owned;
+  std::string err;
+
+  const HostTensor* get(const std::string& name) {
+    auto it = ctx->host_tensors.find(name);
+    if (it == ctx->host_tensors.end()) { if (err.empty()) err = "missing tensor: " + name; return nullptr; }
+    return &it->second;
+  }
+  static uint16_t cvt16(float v, int dtype) {
+    if (dtype == DT_F16) { f16 h = (f16)v; uint16_t u; memcpy(&u, &h, 2); return u; }
+    uint32_t u; memcpy(&u, &v, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+  }
+  DevW upload_T(const std::vector<float>& v) {
+    std::vector<uint16_t> h(v.size());
+    for (size_t i = 0; i < v.size(); ++i) h[i] = cvt16(v[i], ctx->dtype);
+    DevW d; d.n = (int64_t)v.size();
+    if (rt::dev_malloc(&d.p, h.size() * 2 + 256)) { err = "device OOM uploading weights"; return d; }
+    owned->push_back(d.p);
+    rt::memcpy_h2d(d.p, h.data(), h.size() * 2, ctx->stream);
+    rt::stream_sync(ctx->stream);
+    return d;
+  }
+  DevW upload_f32(const std::vector<float>& v) {
+    DevW d; d.n = (int64_t)v.size();
+    if (rt::dev_malloc(&d.p, v.size() * 4 + 256)) { err = "device OOM uploading weights"; return d; }
+    owned->push_back(d.p);
+    rt::memcpy_h2d(d.p, v.data(), v.size() * 4, ctx->stream);
+    rt::stream_sync(ctx->stream);
+    return d;
+  }
+  NormW norm(const std::string& p) {
+    NormW n;
+    const HostTensor* g = get(p + ".weight"); const HostTensor* b = get(p + ".bias");
+    if (!g || !b) return n;
+    n.C = (int)g->data.size(); n.g = upload_f32(g->data); n.b = upload_f32(b->data);
+    return n;
+  }
+  DevW bias(const std::string& name) {
+    const HostTensor* b = get(name);
+    return b ? upload_f32(b->data) : DevW{};
+  }
+  // nn.Linear / 1x1 conv / Conv1d(k=1): weight [N, K, (1,1)] -> [N][K]
+  LinW linear(const std::string& p, bool has_bias = true) {
+    LinW l;
+    const HostTensor* w = get(p + ".weight");
+    if (!w) return l;
+    l.N = (int)w->shape[0]; l.K = (int)(w->data.size() / (size_t)l.N);
+    l.w = upload_T(w->data);
+    if (has_bias) l.b = bias(p + ".bias");
+    return l;
+  }
+  // Conv2d 3x3 [N, C, 3, 3] -> [N][tap][C] (K = 9C, tap-major), tap = ky*3 + kx
+  LinW conv3x3(const std::string& p) {
+    LinW l;
+    const HostTensor* w = get(p + ".weight");
+    if (!w) return l;
+    const int N = (int)w->shape[0], C = (int)w->shape[1];
+    std::vector<float> r((size_t)N * 9 * C);
+    for (int n = 0; n < N; ++n) for (int c = 0; c < C; ++c) for (int t = 0; t < 9; ++t)
+      r[((size_t)n * 9 + t) * C + c] = w->data[((size_t)n * C + c) * 9 + t];
+    l.N = N; l.K = 9 * C; l.w = upload_T(r); l.b = bias(p + ".bias");
+    return l;
+  }
+  // stem-like Conv2d 3x3 with tiny C (4): [N, C, 3, 3] -> [N][64] columns tap*C + c, zero padded (pairs with stem_im2col)
+  LinW conv3x3_im2col64(const std::string& p) {
+    LinW l;
+    const HostTensor* w = get(p + ".weight");
+    if (!w) return l;
+    const int N = (int)w->shape[0], C = (int)w->shape[1];
+    std::vector<float> r((size_t)N * 64, 0.f);
+    for (int n = 0; n < N; ++n) for (int c = 0; c < C; ++c) for (int t = 0; t < 9; ++t)
+      r[(size_t)n * 64 + t * C + c] = w->data[((size_t)n * C + c) * 9 + t];
+    l.N = N; l.K = 64; l.w = upload_T(r); l.b = bias(p + ".bias");
+    return l;
+  }
+  // Conv3d (3,1,1) [N, C, 3, 1, 1] -> [N][tap][C]
+  LinW tconv(const std::string& p) {
+    LinW l;
+    const HostTensor* w = get(p + ".weight");
+    if (!w) return l;
+    const int N = (int)w->shape[0], C = (int)w->shape[1];
+    std::vector<float> r((size_t)N * 3 * C);
+    for (int n = 0; n < N; ++n) for (int c = 0; c < C; ++c) for (int t = 0; t < 3; ++t)
+      r[((size_t)n * 3 + t) * C + c] = w->data[((size_t)n * C + c) * 3 + t];
+    l.N = N; l.K = 3 * C; l.w = upload_T(r); l.b = bias(p + ".bias");
+    return l;
+  }
+  // row-concatenate several [Ni, K] matrices (fused q|k|v)
+  LinW fused(const std::vector<std::string>& names) {
+    LinW l;
+    std::vector<float> r;
+    for (auto& nm : names) {
+      const HostTensor* w = get(nm + ".weight");
+      if (!w) return l;
+      l.K = (int)(w->data.size() / (size_t)w->shape[0]);
+      l.N += (int)w->shape[0];
+      r.insert(r.end(), w->data.begin(), w->data.end());
+    }
+    l.w = upload_T(r);
+    return l;
+  }
+  // GEGLU projection [2H, K] (value rows, gate rows) -> alternating 32-row (value, gate) blocks
+  LinW geglu(const std::string& p) {
+    LinW l;
+    const HostTensor* w = get(p + ".weight"); const HostTensor* b = get(p + ".bias");
+    if (!w || !b) return l;
+    const int N2 = (int)w->shape[0], K = (int)w->shape[1], Hh = N2 / 2;
+    std::vector<float> r((size_t)N2 * K), rb(N2);
+    for (int blk = 0; blk < Hh / 32; ++blk)
+      for (int half = 0; half < 2; ++half)
+        for (int i = 0; i < 32; ++i) {
+          const int src = half * Hh + blk * 32 + i, dst = blk * 64 + half * 32 + i;
+          memcpy(&r[(size_t)dst * K], &w->data[(size_t)src * K], (size_t)K * 4);
+          rb[dst] = b->data[src];
+        }
+    l.N = N2; l.K = K; l.w = upload_T(r); l.b = upload_f32(rb);
+    return l;
+  }
+  DevW raw_f32(const std::string& name) {
+    const HostTensor* t = get(name);
+    return t ? upload_f32(t->data) : DevW{};
+  }
+
+  ResW res(const std::string& p) {
+    ResW r;
+    r.gn1 = norm(p + ".in_layers.0");
+    r.conv1 = conv3x3(p + ".in_layers.2");
+    r.emb = linear(p + ".emb_layers.1");
+    r.gn2 = norm(p + ".out_layers.0");
+    r.conv2 = conv3x3(p + ".out_layers.3");
+    r.cin = r.gn1.C; r.cout = r.gn2.C;
+    r.has_skip = ctx->host_tensors.count(p + ".skip_connection.weight") > 0;
+    if (r.has_skip) r.skip = linear(p + ".skip_connection");
+    const int ci[4] = {2, 3, 3, 3};
+    for (int k = 0; k < 4; ++k) {
+      const std::string q = p + ".temopral_conv.conv" + std::to_string(k + 1);
+      r.tgn[k] = norm(q + ".0");
+      r.tconv[k] = tconv(q + "." + std::to_string(ci[k]));
+    }
+    return r;
+  }
+  TBlockW tblock(const std::string& p, bool spatial) {
+    TBlockW t;
+    t.n1 = norm(p + ".norm1"); t.n2 = norm(p + ".norm2"); t.n3 = norm(p + ".norm3");
+    t.qkv1 = fused({p + ".attn1.to_q", p + ".attn1.to_k", p + ".attn1.to_v"});
+    t.out1 = linear(p + ".attn1.to_out.0");
+    if (spatial) {
+      t.q2 = linear(p + ".attn2.to_q", false);
+      t.kv2 = fused({p + ".attn2.to_k", p + ".attn2.to_v"});
+    } else {
+      t.qkv2 = fused({p + ".attn2.to_q", p + ".attn2.to_k", p + ".attn2.to_v"});
+      t.local2 = raw_f32(p + ".local2.conv1.weight");
+    }
+    t.out2 = linear(p + ".attn2.to_out.0");
+    t.ff1 = geglu(p + ".ff.net.0.proj");
+    t.ff2 = linear(p + ".ff.net.2");
+    t.local1 = raw_f32(p + ".local1.conv1.weight");
+    return t;
+  }
+  STW st(const std::string& p, int heads) {
+    STW s;
+    s.norm = norm(p + ".norm"); s.C = s.norm.C; s.heads = heads;
+    s.proj_in = linear(p + ".proj_in"); s.proj_out = linear(p + ".proj_out");
+    s.tb = tblock(p + ".transformer_blocks.0", true);
+    return s;
+  }
+  TTW tt(const std::string& p, int heads) {
+    TTW s;
+    s.norm = norm(p + ".norm"); s.C = s.norm.C; s.heads = heads;
+    s.proj_in = linear(p + ".proj_in"); s.proj_out = linear(p + ".proj_out");
+    s.inner = s.proj_in.N;
+    s.tb = tblock(p + ".transformer_blocks.0", false);
+    return s;
+  }
+};
+
+// ------------------------------------------------------------------ forward helpers
+struct Act {          // an activation tensor: rows = F*H*W tokens; the buffer returns to the pool with its last owner
+  std::shared_ptr<Buf> buf; int C = 0, H = 0, W = 0;
+  void* p() const { return buf ? buf->p : nullptr; }
+  void drop() { buf.reset(); }
+};
+
+struct Fwd {
+  Ctx* ctx;
+  int F = 0;
+  size_t es = 2;
+  float* emb = nullptr;        // fp32 [E] (device) time embedding of the running net
+  const void* context = nullptr;  // T [77][ctx_dim]
+  int ctx_dim = 0, embed_dim = 0;
+  int rc = 0;
+
+  Act make(int C, int H, int W) {
+    Act a; a.C = C; a.H = H; a.W = W;
+    a.buf = std::make_shared<Buf>(ctx, (size_t)F * H * W * C * es);
+    if (!a.buf->p) { rc = ctx->fail("out of device memory (activations)"); }
+    return a;
+  }
+  int rows(const Act& a) const { return F * a.H * a.W; }
+  void ok(int r) { if (r && !rc) rc = r; }
+
+  // y = x W^T (+b) (+res)
+  void gemm(const void* A, int lda, int M, const LinW& w, void* C, int ldc, const void* res = nullptr, int ldr = 0, int extra_epi = 0,
+            const float* bias_override = nullptr) {
+    GemmArgs g;
+    g.A = A; g.W = w.w.p; g.C = C; g.M = M; g.N = w.N; g.K = w.K; g.lda = lda; g.ldc = ldc;
+    g.bias = bias_override ? bias_override : (const float*)w.b.p;
+    g.res = res; g.ldr = ldr;
+    g.epi = (g.bias ? EPI_BIAS : 0) | (res ? EPI_RES : 0) | extra_epi;
+    ok(op_gemm(ctx, g));
+  }
+  void conv3x3(const Act& x, const LinW& w, Act& y, int mode, int stride, int pad_t, int pad_l, const void* res, const float* bias_override = nullptr,
+               int extra_epi = 0, void* out_override = nullptr, int ldc_override = 0) {
+    GemmArgs g;
+    g.A = x.p(); g.W = w.w.p; g.C = out_override ? out_override : y.p();
+    g.M = F * y.H * y.W; g.N = w.N; g.K = w.K; g.lda = x.C; g.ldc = ldc_override ? ldc_override : y.C;
+    g.mode = mode; g.H = x.H; g.Wd = x.W; g.Cin = x.C; g.Ho = y.H; g.Wo = y.W; g.stride = stride; g.pad_t = pad_t; g.pad_l = pad_l;
+    g.bias = bias_override ? bias_override : (const float*)w.b.p;
+    g.res = res; g.ldr = y.C;
+    g.epi = (g.bias ? EPI_BIAS : 0) | (res ? EPI_RES : 0) | extra_epi;
+    ok(op_gemm(ctx, g));
+  }
+  void gn(const Act& x, const NormW& n, Act& y, bool whole_chunk, float eps, bool silu) {
+    const int rps = whole_chunk ? F * x.H * x.W : x.H * x.W;
+    ok(op_group_norm(ctx, x.p(), x.C, y.p(), y.C, (const float*)n.g.p, (const float*)n.b.p, rows(x), x.C, rps, eps, silu));
+  }
+  void ln(const void* x, void* y, int rws, int C, const NormW& n, int mode = LN_PLAIN, const float* gw = nullptr, float* maps = nullptr, int H = 0, int W = 0) {
+    ok(op_layer_norm(ctx, x, C, y, C, (const float*)n.g.p, (const float*)n.b.p, rws, C, 1e-5f, mode, gw, maps, H, W));
+  }
+
+  // ResBlock._forward + TemporalConvBlock_v2 (unet_v2v.py:666-692, 1266-1277)
+  Act res_block(const ResW& r, Act x) {
+    const int R = rows(x);
+    Act n1 = make(r.cin, x.H, x.W);
+    gn(x, r.gn1, n1, false, 1e-5f, true);
+    // conv bias + Linear(SiLU(emb)) folded into one per-channel vector (batch = 1: same for every frame)
+    Buf bias1(ctx, (size_t)r.cout * 4);
+    ok(op_gemv(ctx, emb, r.emb.w.p, (const float*)r.emb.b.p, bias1.as<float>(), r.cout, r.emb.K, true, false));
+    ok(op_vec_add_f32(ctx, bias1.as<float>(), (const float*)r.conv1.b.p, r.cout));
+    Act h1 = make(r.cout, x.H, x.W);
+    conv3x3(n1, r.conv1, h1, A_CONV3X3, 1, 1, 1, nullptr, bias1.as<float>());
+    n1.drop();
+    Act n2 = make(r.cout, x.H, x.W);
+    gn(h1, r.gn2, n2, false, 1e-5f, true);
+    h1.drop();
+    Act skip;
+    const void* sp = x.p();
+    if (r.has_skip) {
+      skip = make(r.cout, x.H, x.W);
+      gemm(x.p(), x.C, R, r.skip, skip.p(), r.cout);
+      sp = skip.p();
+    }
+    Act h2 = make(r.cout, x.H, x.W);
+    conv3x3(n2, r.conv2, h2, A_CONV3X3, 1, 1, 1, sp);
+    n2.drop(); skip.drop(); x.drop();
+    // temporal conv block: 4 x [GN(whole chunk) + SiLU + Conv3d(3,1,1)] + identity
+    Act cur;  // null => h2
+    for (int k = 0; k < 4; ++k) {
+      const Act& in = (k == 0) ? h2 : cur;
+      Act nn = make(r.cout, h2.H, h2.W);
+      gn(in, r.tgn[k], nn, true, 1e-5f, true);
+      Act nxt = make(r.cout, h2.H, h2.W);
+      GemmArgs g;
+      g.A = nn.p(); g.W = r.tconv[k].w.p; g.C = nxt.p(); g.M = R; g.N = r.cout; g.K = 3 * r.cout; g.lda = r.cout; g.ldc = r.cout;
+      g.mode = A_TCONV3; g.Cin = r.cout; g.HW = h2.H * h2.W; g.F = F;
+      g.bias = (const float*)r.tconv[k].b.p; g.epi = EPI_BIAS;
+      if (k == 3) { g.res = h2.p(); g.ldr = r.cout; g.epi |= EPI_RES; }
+      ok(op_gemm(ctx, g));
+      cur = std::move(nxt);
+    }
+    return cur;
+  }
+
+  // shared tail of both transformer kinds: LN3 -> GEGLU FF -> +res ; then proj_out (+ x_in)
+  void ff_and_out(const TBlockW& tb, Act& h2, int R, int inner, const LinW& proj_out, const Act& x_in, Act& out) {
+    Act l3 = make(inner, x_in.H, x_in.W);
+    ln(h2.p(), l3.p(), R, inner, tb.n3);
+    Buf g(ctx, (size_t)R * inner * 4 * es);
+    if (!g.p) { rc = ctx->fail("out of device memory (ff)"); return; }
+    gemm(l3.p(), inner, R, tb.ff1, g.p, inner * 4, nullptr, 0, EPI_GEGLU);
+    l3.drop();
+    Act h3 = make(inner, x_in.H, x_in.W);
+    gemm(g.p, inner * 4, R, tb.ff2, h3.p(), inner, h2.p(), inner);
+    g.reset(); h2.drop();
+    gemm(h3.p(), inner, R, proj_out, out.p(), out.C, x_in.p(), x_in.C);
+  }
+
+  // SpatialTransformer.forward + BasicTransformerBlock space branch (unet_v2v.py:297-317, 466-477)
+  Act spatial_transformer(const STW& s, Act x) {
+    const int R = rows(x), C = s.C, HW = x.H * x.W;
+    const TBlockW& tb = s.tb;
+    Act n = make(C, x.H, x.W);
+    gn(x, s.norm, n, false, 1e-6f, false);
+    Act h = make(C, x.H, x.W);
+    gemm(n.p(), C, R, s.proj_in, h.p(), C);
+    // LIEM spatial gate + LN1
+    Buf maps(ctx, (size_t)R * 2 * 4);
+    ln(h.p(), nullptr, R, C, tb.n1, LN_STATS_ONLY, nullptr, maps.as<float>());
+    ln(h.p(), n.p(), R, C, tb.n1, LN_GATE_MAP, (const float*)tb.local1.p, maps.as<float>(), x.H, x.W);
+    maps.reset();
+    // self attention over the H*W tokens of each frame
+    Buf qkv(ctx, (size_t)R * 3 * C * es);
+    if (!qkv.p) { rc = ctx->fail("out of device memory (qkv)"); return x; }
+    gemm(n.p(), C, R, tb.qkv1, qkv.p, 3 * C);
+    {
+      AttnArgs a;
+      a.Q = qkv.p; a.K = (char*)qkv.p + (size_t)C * es; a.V = (char*)qkv.p + (size_t)2 * C * es; a.O = n.p();
+      a.ldq = a.ldk = a.ldv = 3 * C; a.ldo = C;
+      a.bsq = a.bsk = a.bsv = (long long)HW * 3 * C; a.bso = (long long)HW * C;
+      a.Nq = a.Nk = HW; a.heads = s.heads; a.batch = F; a.scale = 0.125f;
+      ok(op_flash_attn(ctx, a));
+    }
+    qkv.reset();
+    Act h1 = make(C, x.H, x.W);
+    gemm(n.p(), C, R, tb.out1, h1.p(), C, h.p(), C);
+    h.drop();
+    // cross attention to the text context (shared by all frames)
+    ln(h1.p(), n.p(), R, C, tb.n2);
+    Act q2 = make(C, x.H, x.W);
+    gemm(n.p(), C, R, tb.q2, q2.p(), C);
+    Buf kv(ctx, (size_t)77 * 2 * C * es);
+    gemm(context, ctx_dim, 77, tb.kv2, kv.p, 2 * C);
+    {
+      AttnArgs a;
+      a.Q = q2.p(); a.K = kv.p; a.V = (char*)kv.p + (size_t)C * es; a.O = n.p();
+      a.ldq = C; a.ldk = a.ldv = 2 * C; a.ldo = C;
+      a.bsq = a.bso = (long long)HW * C; a.bsk = a.bsv = 0;
+      a.Nq = HW; a.Nk = 77; a.heads = s.heads; a.batch = F; a.scale = 0.125f;
+      ok(op_flash_attn(ctx, a));
+    }
+    q2.drop(); kv.reset();
+    Act h2 = make(C, x.H, x.W);
+    gemm(n.p(), C, R, tb.out2, h2.p(), C, h1.p(), C);
+    h1.drop(); n.drop();
+    Act out = make(C, x.H, x.W);
+    ff_and_out(tb, h2, R, C, s.proj_out, x, out);
+    return out;
+  }
+
+  // TemporalTransformer.forward + BasicTransformerBlock temp branch (unet_v2v.py:1034-1092, 479-490)
+  Act temporal_transformer(const TTW& s, Act x) {
+    const int R = rows(x), C = s.C, I = s.inner, HW = x.H * x.W;
+    const TBlockW& tb = s.tb;
+    Act n = make(C, x.H, x.W);
+    gn(x, s.norm, n, true, 1e-6f, false);
+    Act h = make(I, x.H, x.W);
+    gemm(n.p(), C, R, s.proj_in, h.p(), I);
+    n.drop();
+    Act l = make(I, x.H, x.W);
+    Buf qkv(ctx, (size_t)R * 3 * I * es);
+    if (!qkv.p) { rc = ctx->fail("out of device memory (qkv)"); return x; }
+    Act cur = std::move(h);
+    for (int pass = 0; pass < 2; ++pass) {
+      ln(cur.p(), l.p(), R, I, pass == 0 ? tb.n1 : tb.n2, LN_GATE_LINEAR, (const float*)(pass == 0 ? tb.local1.p : tb.local2.p));
+      gemm(l.p(), I, R, pass == 0 ? tb.qkv1 : tb.qkv2, qkv.p, 3 * I);
+      TAttnArgs a;
+      a.Q = qkv.p; a.K = (char*)qkv.p + (size_t)I * es; a.V = (char*)qkv.p + (size_t)2 * I * es; a.O = l.p();
+      a.ldq = a.ldk = a.ldv = 3 * I; a.ldo = I; a.F = F; a.HW = HW; a.heads = s.heads; a.scale = 0.125f;
+      ok(op_temporal_attn(ctx, a));
+      Act nx = make(I, x.H, x.W);
+      gemm(l.p(), I, R, pass == 0 ? tb.out1 : tb.out2, nx.p(), I, cur.p(), I);
+      cur = std::move(nx);
+    }
+    qkv.reset(); l.drop();
+    Act out = make(C, x.H, x.W);
+    ff_and_out(tb, cur, R, I, s.proj_out, x, out);
+    return out;
+  }
+
+  Act down(const ConvW& c, Act x) {   // Downsample: conv 3x3 stride 2 padding (2,1) (unet_v2v.py:709-722)
+    Act y = make(c.C, x.H / 2 + 1, x.W / 2);
+    if ((x.H + 4 - 3) / 2 + 1 != y.H || (x.W + 2 - 3) / 2 + 1 != y.W) { rc = ctx->fail("downsample: illegal latent size"); return y; }
+    conv3x3(x, c.conv, y, A_CONV3X3, 2, 2, 1, nullptr);
+    return y;
+  }
+  Act up(const ConvW& c, Act x) {     // Upsample: nearest x2, rows [1:-1], conv 3x3 (unet_v2v.py:556-567)
+    Act y = make(c.C, 2 * x.H - 2, 2 * x.W);
+    conv3x3(x, c.conv, y, A_CONV3X3_UP, 1, 1, 1, nullptr);
+    return y;
+  }
+  Act run(const Net& net, const Mod& m, Act x) {
+    switch (m.kind) {
+      case M_RES: return res_block(net.res[m.idx], std::move(x));
+      case M_ST: return spatial_transformer(net.st[m.idx], std::move(x));
+      case M_TT: return temporal_transformer(net.tt[m.idx], std::move(x));
+      case M_DOWN: return down(net.convs[m.idx], std::move(x));
+      case M_UP: return up(net.convs[m.idx], std::move(x));
+    }
+    rc = ctx->fail("bad module kind");
+    return x;
+  }
+};
+
+static void host_sinusoidal(long long t, int dim, std::vector<float>& out) {   // unet_v2v.py:96-108
+  const int half = dim / 2;
+  out.assign(dim, 0.f);
+  for (int i = 0; i < half; ++i) {
+    const float freq = powf(10000.f, -(float)i / (float)half);
+    const float s = (float)t * freq;
+    out[i] = cosf(s);
+    out[half + i] = sinf(s);
+  }
+}
+
+static int build_net(Builder& b, const UNetCfg& cfg, bool control, Net& net) {
+  const std::string P = control ? "VideoControlNet." : "";
+  net.time0 = b.linear(P + "time_embed.0");
+  net.time2 = b.linear(P + "time_embed.2");
+  net.stem = b.conv3x3_im2col64(P + "input_blocks.0.0");
+  const int hd = cfg.head_dim;
+  std::vector<int> enc; enc.push_back(cfg.dim);
+  for (int i = 0; i < cfg.n_levels; ++i) enc.push_back(cfg.dim * cfg.dim_mult[i]);
+  std::vector<int> shortcut;
+  std::vector<int> zero_dims;
+  // block 0: stem conv (separate) + stem TemporalTransformer
+  {
+    net.tt.push_back(b.tt(P + "input_blocks.0.1", cfg.num_heads));
+    net.input_blocks.push_back({Mod{M_TT, (int)net.tt.size() - 1}});
+    shortcut.push_back(cfg.dim); zero_dims.push_back(cfg.dim);
+  }
+  int idx = 1, level = 0;
+  for (int i = 0; i < cfg.n_levels; ++i) {
+    for (int j = 0; j < cfg.num_res_blocks; ++j) {
+      const int cout = enc[i + 1];
+      const std::string bp = P + "input_blocks." + std::to_string(idx);
+      std::vector<Mod> mods;
+      net.res.push_back(b.res(bp + ".0")); mods.push_back(Mod{M_RES, (int)net.res.size() - 1});
+      if (level < cfg.attn_levels) {
+        net.st.push_back(b.st(bp + ".1", cout / hd)); mods.push_back(Mod{M_ST, (int)net.st.size() - 1});
+        net.tt.push_back(b.tt(bp + ".2", cout / hd)); mods.push_back(Mod{M_TT, (int)net.tt.size() - 1});
+      }
+      net.input_blocks.push_back(mods);
+      shortcut.push_back(cout); zero_dims.push_back(cout);
+      ++idx;
+      if (i != cfg.n_levels - 1 && j == cfg.num_res_blocks - 1) {
+        ConvW c; c.C = cout; c.conv = b.conv3x3(P + "input_blocks." + std::to_string(idx) + ".op");
+        net.convs.push_back(c);
+        net.input_blocks.push_back({Mod{M_DOWN, (int)net.convs.size() - 1}});
+        shortcut.push_back(cout); zero_dims.push_back(cout);
+        ++level; ++idx;
+      }
+    }
+  }
+  const int cm = enc.back();
+  net.res.push_back(b.res(P + "middle_block.0")); net.middle.push_back(Mod{M_RES, (int)net.res.size() - 1});
+  net.st.push_back(b.st(P + "middle_block.1", cm / hd)); net.middle.push_back(Mod{M_ST, (int)net.st.size() - 1});
+  net.tt.push_back(b.tt(P + "middle_block.2", cm / hd)); net.middle.push_back(Mod{M_TT, (int)net.tt.size() - 1});
+  net.res.push_back(b.res(P + "middle_block.3")); net.middle.push_back(Mod{M_RES, (int)net.res.size() - 1});
+  if (control) {
+    for (size_t i = 0; i < zero_dims.size(); ++i) net.zero_convs.push_back(b.linear(P + "zero_convs." + std::to_string(i) + ".0"));
+    net.middle_out = b.linear(P + "middle_block_out.0");
+    net.hint = b.conv3x3_im2col64(P + "input_hint_block");
+  } else {
+    int oidx = 0;
+    for (int i = 0; i < cfg.n_levels; ++i) {
+      const int cout = cfg.dim * cfg.dim_mult[cfg.n_levels - 1 - i];
+      for (int j = 0; j < cfg.num_res_blocks + 1; ++j) {
+        const std::string bp = "output_blocks." + std::to_string(oidx);
+        std::vector<Mod> mods;
+        net.res.push_back(b.res(bp + ".0")); mods.push_back(Mod{M_RES, (int)net.res.size() - 1});
+        int k = 1;
+        if (level < cfg.attn_levels) {
+          net.st.push_back(b.st(bp + ".1", cout / hd)); mods.push_back(Mod{M_ST, (int)net.st.size() - 1});
+          net.tt.push_back(b.tt(bp + ".2", cout / hd)); mods.push_back(Mod{M_TT, (int)net.tt.size() - 1});
+          k = 3;
+        }
+        if (i != cfg.n_levels - 1 && j == cfg.num_res_blocks) {
+          ConvW c; c.C = cout; c.conv = b.conv3x3(bp + "." + std::to_string(k) + ".conv");
+          net.convs.push_back(c); mods.push_back(Mod{M_UP, (int)net.convs.size() - 1});
+          --level;
+        }
+        net.output_blocks.push_back(mods);
+        ++oidx;
+      }
+    }
+    net.out_norm = b.norm("out.0");
+    net.out_conv = b.conv3x3("out.2");
+  }
+  return b.err.empty() ? 0 : 1;
+}
+
+}  // namespace
+
+int unet_build(Ctx* ctx, const UNetCfg& cfg) {
+  auto model = std::make_shared<UNetModel>();
+  model->cfg = cfg;
+  Builder b{ctx, &model->owned, ""};
+  if (build_net(b, cfg, false, model->main) || build_net(b, cfg, true, model->control)) return ctx->fail("unet_build: " + b.err);
+  if (!b.err.empty()) return ctx->fail("unet_build: " + b.err);
+  ctx->unet = model;
+  ctx->host_tensors.clear();
+  return 0;
+}
+
+static int time_embedding(Ctx* ctx, const Net& net, long long t, int dim, int E, Buf& tmp_in, Buf& tmp_mid, float* out) {
+  std::vector<float> se;
+  host_sinusoidal(t, dim, se);
+  rt::memcpy_h2d(tmp_in.p, se.data(), (size_t)dim * 4, ctx->stream);
+  rt::stream_sync(ctx->stream);  // `se` is a stack temporary
+  if (op_gemv(ctx, tmp_in.as<float>(), net.time0.w.p, (const float*)net.time0.b.p, tmp_mid.as<float>(), E, dim, false, true)) return 1;
+  return op_gemv(ctx, tmp_mid.as<float>(), net.time2.w.p, (const float*)net.time2.b.p, out, E, E, false, false);
+}
+
+int unet_forward(Ctx* ctx, const float* xt, long long t, const float* y, const float* hint, float* out, int F, int H, int W) {
+  if (!ctx->unet) return ctx->fail("unet_forward: no model built (star_unet_build)");
+  const UNetModel& M = *ctx->unet;
+  const UNetCfg& cfg = M.cfg;
+  if (F < 1 || F > 64) return ctx->fail("unet_forward: 1..64 frames per chunk");
+  {  // legal latent sizes: every Downsample/Upsample pair must round-trip (H = 2 mod 8, W = 0 mod 8 for 3 levels)
+    int h = H, w = W;
+    for (int i = 0; i < cfg.n_levels - 1; ++i) { if (w % 2) return ctx->fail("unet_forward: illegal latent width"); h = h / 2 + 1; w /= 2; }
+    for (int i = 0; i < cfg.n_levels - 1; ++i) { h = 2 * h - 2; w *= 2; }
+    if (h != H || w != W) return ctx->fail("unet_forward: illegal latent size (need H = 2 mod 8, W = 0 mod 8)");
+  }
+  Fwd f; f.ctx = ctx; f.F = F; f.es = ctx->esize(); f.ctx_dim = cfg.context_dim; f.embed_dim = cfg.embed_dim();
+  const int E = cfg.embed_dim();
+  const long long tok = (long long)F * H * W;
+  Buf ctxT(ctx, (size_t)77 * cfg.context_dim * f.es);
+  if (op_cast(ctx, y, ctxT.p, (long long)77 * cfg.context_dim)) return 1;
+  f.context = ctxT.p;
+  Buf emb_main(ctx, (size_t)E * 4), emb_ctrl(ctx, (size_t)E * 4), t_in(ctx, (size_t)cfg.dim * 4), t_mid(ctx, (size_t)E * 4);
+  if (time_embedding(ctx, M.main, t, cfg.dim, E, t_in, t_mid, emb_main.as<float>())) return 1;
+  if (time_embedding(ctx, M.control, t, cfg.dim, E, t_in, t_mid, emb_ctrl.as<float>())) return 1;
+
+  // im2col rows of x (shared by both nets' stem convs) and of the hint
+  Buf xcols(ctx, (size_t)tok * 64 * f.es), hcols(ctx, (size_t)tok * 64 * f.es);
+  if (!xcols.p || !hcols.p) return ctx->fail("out of device memory");
+  if (op_stem_im2col(ctx, xt, xcols.p, cfg.in_dim, F, H, W)) return 1;
+  if (op_stem_im2col(ctx, hint, hcols.p, 4, F, H, W)) return 1;
+
+  // ---------------- VideoControlNet (unet_v2v.py:2134-2206)
+  std::vector<Act> control;
+  {
+    const Net& net = M.control;
+    f.emb = emb_ctrl.as<float>();
+    Act hc = f.make(cfg.dim, H, W);
+    f.gemm(hcols.p, 64, (int)tok, net.hint, hc.p(), cfg.dim);
+    hcols.reset();
+    Act x = f.make(cfg.dim, H, W);
+    f.gemm(xcols.p, 64, (int)tok, net.stem, x.p(), cfg.dim, hc.p(), cfg.dim);   // stem conv + hint (added before the stem TT, :2190-2194)
+    hc.drop();
+    for (size_t bi = 0; bi < net.input_blocks.size(); ++bi) {
+      for (const Mod& m : net.input_blocks[bi]) x = f.run(net, m, std::move(x));
+      if (f.rc) return f.rc;
+      Act z = f.make(x.C, x.H, x.W);
+      f.gemm(x.p(), x.C, f.rows(x), net.zero_convs[bi], z.p(), x.C);
+      control.push_back(std::move(z));
+    }
+    for (const Mod& m : net.middle) x = f.run(net, m, std::move(x));
+    if (f.rc) return f.rc;
+    Act z = f.make(x.C, x.H, x.W);
+    f.gemm(x.p(), x.C, f.rows(x), net.middle_out, z.p(), x.C);
+    control.push_back(std::move(z));
+  }
+  // ---------------- main UNet (unet_v2v.py:1765-1808)
+  const Net& net = M.main;
+  f.emb = emb_main.as<float>();
+  std::vector<Act> xs;
+  Act x = f.make(cfg.dim, H, W);
+  f.gemm(xcols.p, 64, (int)tok, net.stem, x.p(), cfg.dim);
+  xcols.reset();
+  for (size_t bi = 0; bi < net.input_blocks.size(); ++bi) {
+    for (const Mod& m : net.input_blocks[bi]) x = f.run(net, m, std::move(x));
+    if (f.rc) return f.rc;
+    xs.push_back(x);   // skip connection shares the buffer
+  }
+  for (const Mod& m : net.middle) x = f.run(net, m, std::move(x));
+  if (f.rc) return f.rc;
+  {
+    Act s = f.make(x.C, x.H, x.W);
+    f.ok(op_add(ctx, control.back().p(), x.p(), s.p(), (long long)f.rows(x) * x.C));
+    control.pop_back();
+    x = std::move(s);
+  }
+  for (size_t bi = 0; bi < net.output_blocks.size(); ++bi) {
+    Act& skip = xs.back(); Act& ctl = control.back();
+    Act cat = f.make(x.C + skip.C, x.H, x.W);
+    if (skip.H != x.H || skip.W != x.W) return ctx->fail("unet_forward: skip shape mismatch");
+    f.ok(op_concat_add(ctx, x.p(), skip.p(), ctl.p(), cat.p(), f.rows(x), x.C, skip.C));
+    xs.pop_back(); control.pop_back();
+    x = std::move(cat);
+    for (const Mod& m : net.output_blocks[bi]) x = f.run(net, m, std::move(x));
+    if (f.rc) return f.rc;
+  }
+  // head: GN + SiLU + conv 3x3 -> out_dim, fp32 rows, then back to [1, C, F, H, W]
+  Act n = f.make(x.C, x.H, x.W);
+  f.gn(x, net.out_norm, n, false, 1e-5f, true);
+  x.drop();
+  Buf rowsf(ctx, (size_t)tok * 8 * 4);
+  Act dummy; dummy.C = 8; dummy.H = H; dummy.W = W;
+  f.conv3x3(n, net.out_conv, dummy, A_CONV3X3, 1, 1, 1, nullptr, nullptr, EPI_OUT_F32, rowsf.p, 8);
+  f.ok(op_rows_to_latent(ctx, rowsf.as<float>(), out, cfg.out_dim, 8, tok));
+  return f.rc;
+}
+
+int module_run(Ctx* ctx, int kind, const char* prefix, int cin, int cout, int heads, int embed_dim, int context_dim,
+               const void* x, const float* emb, const float* context, void* out, int F, int H, int W) {
+  UNetModel tmp;
+  Builder b{ctx, &tmp.owned, ""};
+  Fwd f; f.ctx = ctx; f.F = F; f.es = ctx->esize(); f.ctx_dim = context_dim; f.embed_dim = embed_dim;
+  f.emb = const_cast<float*>(emb);
+  Buf ctxT;
+  if (context) {
+    ctxT = Buf(ctx, (size_t)77 * context_dim * f.es);
+    if (op_cast(ctx, context, ctxT.p, (long long)77 * context_dim)) return 1;
+    f.context = ctxT.p;
+  }
+  Act xin = f.make(cin, H, W);
+  rt::memcpy_d2d(xin.p(), x, (size_t)F * H * W * cin * f.es, ctx->stream);
+  Act y;
+  const std::string p(prefix);
+  Net net;
+  if (kind == M_RES) { net.res.push_back(b.res(p)); if (!b.err.empty()) return ctx->fail(b.err); y = f.res_block(net.res[0], std::move(xin)); }
+  else if (kind == M_ST) { net.st.push_back(b.st(p, heads)); if (!b.err.empty()) return ctx->fail(b.err); y = f.spatial_transformer(net.st[0], std::move(xin)); }
+  else if (kind == M_TT) { net.tt.push_back(b.tt(p, heads)); if (!b.err.empty()) return ctx->fail(b.err); y = f.temporal_transformer(net.tt[0], std::move(xin)); }
+  else if (kind == M_DOWN) { ConvW c; c.C = cout; c.conv = b.conv3x3(p + ".op"); if (!b.err.empty()) return ctx->fail(b.err); y = f.down(c, std::move(xin)); }
+  else if (kind == M_UP) { ConvW c; c.C = cout; c.conv = b.conv3x3(p + ".conv"); if (!b.err.empty()) return ctx->fail(b.err); y = f.up(c, std::move(xin)); }
+  else return ctx->fail("module_run: bad kind");
+  if (f.rc) return f.rc;
+  rt::memcpy_d2d(out, y.p(), (size_t)F * y.H * y.W * y.C * f.es, ctx->stream);
+  rt::stream_sync(ctx->stream);   // tmp weights are freed on return
+  return 0;
+}
+
+}  // namespace star

@@ -1,0 +1,78 @@
+// unet.h -- host-side model of ControlledV2VUNet + VideoControlNet for the C++ graph executor.
+#pragma once
+#include "ops.h"
+#include <string>
+#include <vector>
+
+namespace star {
+
+struct UNetCfg {
+  int in_dim = 4, dim = 320, context_dim = 1024, out_dim = 4;
+  int n_levels = 4;
+  int dim_mult[8] = {1, 2, 4, 4, 0, 0, 0, 0};
+  int num_heads = 8, head_dim = 64, num_res_blocks = 2;
+  int attn_levels = 3;   // levels 0..attn_levels-1 carry transformers (attn_scales 1, 1/2, 1/4)
+  int embed_dim() const { return dim * 4; }
+};
+
+struct DevW {            // a device-resident parameter tensor
+  void* p = nullptr;
+  int64_t n = 0;
+};
+struct LinW { DevW w; DevW b; int N = 0, K = 0; };   // w: T [N][K]; b: fp32 [N] (may be empty)
+struct NormW { DevW g, b; int C = 0; };               // fp32
+
+struct ResW {
+  int cin = 0, cout = 0;
+  NormW gn1, gn2;
+  LinW conv1, conv2, emb, skip;
+  bool has_skip = false;
+  NormW tgn[4];
+  LinW tconv[4];
+};
+struct TBlockW {
+  NormW n1, n2, n3;
+  LinW qkv1, out1;       // self attention (fused q|k|v rows)
+  LinW q2, kv2, qkv2, out2;  // spatial: q2 + kv2 (context); temporal: qkv2 (self)
+  LinW ff1, ff2;         // ff1 GEGLU-interleaved
+  DevW local1, local2;   // fp32 LIEM gate weights
+};
+struct STW { int C = 0, heads = 0; NormW norm; LinW proj_in, proj_out; TBlockW tb; };
+struct TTW { int C = 0, inner = 0, heads = 0; NormW norm; LinW proj_in, proj_out; TBlockW tb; };
+struct ConvW { int C = 0; LinW conv; };
+
+enum ModKind : int { M_RES = 0, M_ST = 1, M_TT = 2, M_DOWN = 3, M_UP = 4 };
+struct Mod { int kind; int idx; };
+
+struct Net {
+  LinW time0, time2;
+  LinW stem;             // im2col K = 64
+  std::vector<std::vector<Mod>> input_blocks;   // block 0 = [TT] (stem conv handled separately)
+  std::vector<Mod> middle;
+  std::vector<std::vector<Mod>> output_blocks;
+  std::vector<ResW> res;
+  std::vector<STW> st;
+  std::vector<TTW> tt;
+  std::vector<ConvW> convs;
+  // control net only
+  std::vector<LinW> zero_convs;
+  LinW middle_out, hint;
+  // main net only
+  NormW out_norm;
+  LinW out_conv;
+};
+
+struct UNetModel {
+  UNetCfg cfg;
+  Net main, control;
+  std::vector<void*> owned;   // device allocations
+  ~UNetModel();
+};
+
+int unet_build(Ctx* ctx, const UNetCfg& cfg);
+int unet_forward(Ctx* ctx, const float* xt, long long t, const float* y, const float* hint, float* out, int F, int H, int W);
+// run one module built on the fly from staged tensors `prefix.*` (unit parity against reference blocks)
+int module_run(Ctx* ctx, int kind, const char* prefix, int cin, int cout, int heads, int embed_dim, int context_dim,
+               const void* x, const float* emb, const float* context, void* out, int F, int H, int W);
+
+}  // namespace star

@@ -1,0 +1,1 @@
+from .unet_v2v import ControlledV2VUNet  # noqa: F401

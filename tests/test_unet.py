@@ -1,0 +1,132 @@
+"""Block-level and whole-UNet parity of the HIP graph executor (through the C ABI) against
+(a) fixtures produced by the REFERENCE's own code (tests/golden, oracle/make_golden.py) and
+(b) the CPU oracle restatement (oracle/unet_oracle.py) on fresh seeded inputs.
+
+Tolerance: the reference GPU path is fp16 autocast; we compare the 16-bit HIP path with the fp32 CPU
+result as relative RMS error and PSNR over the output range (stated per test)."""
+import glob
+import math
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import unet_oracle as O  # noqa: E402
+from make_golden import unet_inputs  # noqa: E402
+from star_amd.modules.unet_v2v import ControlledV2VUNet, run_module  # noqa: E402
+from star_amd.topology import SMALL_TEST_CONFIG, UNetConfig, random_state_dict  # noqa: E402
+from util import BACKENDS, make_ctx  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+torch.set_grad_enabled(False)
+
+# relative RMS error budget of one block / a whole forward at 16-bit activations with fp32 accumulation
+REL_RMS = {torch.float16: (2e-3, 1e-2), torch.bfloat16: (1.5e-2, 8e-2)}
+
+
+def rel_rms(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt().clamp_min(1e-12))
+
+
+def psnr(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    rng = float(b.max() - b.min())
+    mse = float((a - b).pow(2).mean())
+    return 10 * math.log10(rng * rng / max(mse, 1e-30))
+
+
+@pytest.fixture(params=BACKENDS)
+def backend(request):
+    return request.param
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+def test_blocks_match_reference_fixture(backend, dtype, request):
+    """ResBlock / SpatialTransformer / TemporalTransformer / Downsample / Upsample outputs of the reference modules."""
+    emu = request.getfixturevalue("emu_lib") if backend == "emu" else None
+    ctx = make_ctx(backend, dtype, emu)
+    blocks = torch.load(os.path.join(GOLD, "blocks.pt"))
+    for name, b in blocks.items():
+        kind = b["kind"]
+        emb = b["emb"][0] if kind == "res" else None
+        context = b["context"][0] if kind == "st" else None
+        y = run_module(ctx, kind, b["sd"], "m", b["x"], emb=emb, context=context, heads=2, cout=b["y"].shape[1])
+        err = rel_rms(y, b["y"])
+        assert y.shape == b["y"].shape and torch.isfinite(y).all(), name
+        assert err < REL_RMS[dtype][0] * 2, (name, err)
+    ctx.close()
+
+
+def _small_model(backend, dtype, request):
+    emu = request.getfixturevalue("emu_lib") if backend == "emu" else None
+    net = ControlledV2VUNet(SMALL_TEST_CONFIG, dtype=dtype, library=emu)
+    net.load_state_dict(random_state_dict(SMALL_TEST_CONFIG, seed=0))
+    return net
+
+
+SMALL_GOLD = sorted(glob.glob(os.path.join(GOLD, "unet_small_*.pt")))
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+def test_small_unet_matches_reference_golden(backend, dtype, request):
+    """Reduced-width (dim 64) ControlledV2VUNet: reference forward outputs stored by make_golden.py."""
+    net = _small_model(backend, dtype, request)
+    for path in SMALL_GOLD:
+        gold = torch.load(path)
+        f, h, w, seed = gold["case"]
+        if backend == "emu" and (f * h * w > 100 or dtype == torch.bfloat16 and f * h * w > 80) and os.environ.get("STAR_SLOW") != "1":
+            continue
+        x, t, y, hint = unet_inputs(SMALL_TEST_CONFIG, f, h, w, seed)
+        dev = net.ctx.torch_device
+        out = net(x.to(dev), t=t, y=y.to(dev), hint=hint.to(dev))
+        e = rel_rms(out, gold["out"])
+        assert e < REL_RMS[dtype][1], (os.path.basename(path), e, psnr(out, gold["out"]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+def test_small_unet_matches_oracle_fresh_inputs(dtype):
+    """HIP vs the CPU oracle on shapes without a stored fixture (incl. a 40-frame chunk and a wide latent)."""
+    net = ControlledV2VUNet(SMALL_TEST_CONFIG, dtype=dtype)
+    sd = random_state_dict(SMALL_TEST_CONFIG, seed=1)
+    net.load_state_dict(sd)
+    for (f, h, w, seed) in [(40, 10, 8, 301), (2, 26, 24, 302), (16, 18, 8, 303)]:
+        x, t, y, hint = unet_inputs(SMALL_TEST_CONFIG, f, h, w, seed)
+        ref = O.unet_forward(sd, SMALL_TEST_CONFIG, x, t, y, hint)
+        out = net(x.cuda(), t=t, y=y.cuda(), hint=hint.cuda())
+        e = rel_rms(out, ref)
+        assert e < REL_RMS[dtype][1], ((f, h, w), e)
+
+
+@pytest.mark.gpu
+def test_full_unet_matches_reference_golden():
+    """The full 2.04 B-parameter model (all real channel widths) on a tiny latent, fp16, against the
+    reference's own output (tests/golden/unet_full_f2_10x8.pt); weights regenerated from the seed."""
+    path = os.path.join(GOLD, "unet_full_f2_10x8.pt")
+    if not os.path.isfile(path):
+        pytest.skip("full-size fixture not generated")
+    gold = torch.load(path)
+    f, h, w, seed = gold["case"]
+    cfg = UNetConfig()
+    net = ControlledV2VUNet(cfg, dtype=torch.float16)
+    sd = random_state_dict(cfg, seed=gold["wseed"])
+    net.load_state_dict(sd)
+    del sd
+    net.release_host_weights()
+    x, t, y, hint = unet_inputs(cfg, f, h, w, seed)
+    out = net(x.cuda(), t=t, y=y.cuda(), hint=hint.cuda())
+    e = rel_rms(out, gold["out"])
+    assert e < REL_RMS[torch.float16][1], (e, psnr(out, gold["out"]))
+
+
+def test_illegal_latent_size_is_rejected(backend, request):
+    from star_amd.lib import StarError
+    net = _small_model(backend, torch.float16, request)
+    x, t, y, hint = unet_inputs(SMALL_TEST_CONFIG, 2, 12, 8, 1)
+    dev = net.ctx.torch_device
+    with pytest.raises(StarError):
+        net(x.to(dev), t=t, y=y.to(dev), hint=hint.to(dev))
