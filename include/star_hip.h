@@ -48,6 +48,7 @@ typedef struct star_gemm_desc {
   int32_t mode;                      /* STAR_A_* */
   int32_t H, Wd, Cin, Ho, Wo, stride, pad_t, pad_l;   /* conv geometry, NHWC */
   int32_t HW, F;                     /* temporal-conv geometry */
+  int32_t up_crop;                   /* STAR_A_CONV3X3_UP: rows cropped top+bottom after the 2x upsample (1 UNet, 0 VAE) */
   int32_t epi;                       /* STAR_EPI_* */
   int32_t force_tile;                /* 0 = auto */
 } star_gemm_desc;
@@ -117,6 +118,18 @@ int star_module_run(star_ctx* ctx, int32_t kind, const char* prefix, int32_t cin
                     int32_t embed_dim, int32_t context_dim, const void* x, const float* emb, const float* context,
                     void* out, int32_t f, int32_t h, int32_t w);
 int star_clear_staged(star_ctx* ctx);
+
+/* ---- SVD temporal VAE (B3: vae.encode / vae.decode, video_to_video_model.py:141-161; diffusers un-vendored) ---- */
+typedef struct star_vae_config {
+  int32_t in_ch, out_ch, latent, n_blocks; int32_t block_out[8]; int32_t layers_per_block;
+} star_vae_config;
+/* build from staged tensors named as diffusers' AutoencoderKLTemporalDecoder state dict */
+int star_vae_build(star_ctx* ctx, const star_vae_config* cfg);
+/* replaces: vae.encode(x).latent_dist -> moments rows fp32 [n*h*w, 2*latent] = (mean | logvar), one frame per pass */
+int star_vae_encode(star_ctx* ctx, const float* x, float* moments, int32_t n, int32_t H, int32_t W);
+/* replaces: vae.decode(z, num_frames=n).sample for ONE temporal group of n frames; z fp32 [n, latent, h, w] */
+int star_vae_decode(star_ctx* ctx, const float* z, float* out, int32_t n, int32_t h, int32_t w);
+int star_softmax_rows(star_ctx* ctx, const float* s, int32_t lds, void* p, int32_t ldp, int32_t rows, int32_t n, float scale);
 
 #ifdef __cplusplus
 }

@@ -2,6 +2,7 @@
 #include "../../include/star_hip.h"
 #include "ops.h"
 #include "unet.h"
+#include "vae.h"
 #include <cstring>
 
 using namespace star;
@@ -60,7 +61,7 @@ int star_gemm(star_ctx* h, const star_gemm_desc* d) {
   a.A = d->A; a.W = d->W; a.C = d->C; a.bias = d->bias; a.res = d->res;
   a.M = d->M; a.N = d->N; a.K = d->K; a.lda = d->lda; a.ldc = d->ldc; a.ldr = d->ldr;
   a.mode = d->mode; a.H = d->H; a.Wd = d->Wd; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo;
-  a.stride = d->stride; a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.HW = d->HW; a.F = d->F;
+  a.stride = d->stride; a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.HW = d->HW; a.F = d->F; a.up_crop = d->up_crop;
   a.epi = d->epi; a.force_tile = d->force_tile;
   return op_gemm(&h->c, a);
 }
@@ -136,6 +137,22 @@ int star_unet_forward(star_ctx* h, const float* xt, int64_t t, const float* y, c
 int star_module_run(star_ctx* h, int32_t kind, const char* prefix, int32_t cin, int32_t cout, int32_t heads, int32_t embed_dim,
                     int32_t context_dim, const void* x, const float* emb, const float* context, void* out, int32_t f, int32_t hh, int32_t w) {
   return module_run(&h->c, kind, prefix, cin, cout, heads, embed_dim, context_dim, x, emb, context, out, f, hh, w);
+}
+
+
+int star_vae_build(star_ctx* h, const star_vae_config* c) {
+  VaeCfg cfg;
+  cfg.in_ch = c->in_ch; cfg.out_ch = c->out_ch; cfg.latent = c->latent; cfg.n_blocks = c->n_blocks;
+  for (int i = 0; i < 8; ++i) cfg.block_out[i] = c->block_out[i];
+  cfg.layers_per_block = c->layers_per_block;
+  if (cfg.n_blocks < 1 || cfg.n_blocks > 8) return h->c.fail("vae_build: bad n_blocks");
+  for (int i = 0; i < cfg.n_blocks; ++i) if (cfg.block_out[i] % 64) return h->c.fail("vae_build: block_out channels must be multiples of 64");
+  return vae_build(&h->c, cfg);
+}
+int star_vae_encode(star_ctx* h, const float* x, float* moments, int32_t n, int32_t H, int32_t W) { return vae_encode(&h->c, x, moments, n, H, W); }
+int star_vae_decode(star_ctx* h, const float* z, float* out, int32_t n, int32_t hh, int32_t w) { return vae_decode(&h->c, z, out, n, hh, w); }
+int star_softmax_rows(star_ctx* h, const float* s, int32_t lds, void* p, int32_t ldp, int32_t rows, int32_t n, float scale) {
+  return op_softmax_rows(&h->c, s, lds, p, ldp, rows, n, scale);
 }
 
 }  // extern "C"

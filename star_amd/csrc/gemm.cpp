@@ -10,7 +10,7 @@ static int launch_gemm_t(Ctx* ctx, const GemmArgs& a) {
   p.A = a.A; p.W = a.W; p.C = a.C; p.bias = a.bias; p.res = a.res; p.zero_page = ctx->zero_page;
   p.M = a.M; p.N = a.N; p.K = a.K; p.lda = a.lda; p.ldc = a.ldc; p.ldr = a.ldr;
   p.H = a.H; p.Wd = a.Wd; p.Cin = a.Cin; p.Ho = a.Ho; p.Wo = a.Wo; p.stride = a.stride; p.pad_t = a.pad_t; p.pad_l = a.pad_l;
-  p.HW = a.HW; p.F = a.F; p.epi = a.epi;
+  p.HW = a.HW; p.F = a.F; p.up_crop = a.up_crop; p.epi = a.epi;
   p.tiles_m = (a.M + BM - 1) / BM;
   p.tiles_n = (a.N + BN - 1) / BN;
   const size_t smem = 2 * (size_t)(BM + BN) * 128;
@@ -49,6 +49,7 @@ int op_gemm(Ctx* ctx, const GemmArgs& a) {
   if (a.lda % 8 != 0) return ctx->fail("gemm: lda must be a multiple of 8");
   if (a.mode != A_PLAIN && a.Cin % 64 != 0) return ctx->fail("gemm: conv Cin must be a multiple of 64");
   if ((a.epi & EPI_GEGLU) && (a.N % 64 != 0)) return ctx->fail("gemm: GEGLU needs N % 64 == 0");
+  if ((a.epi & EPI_GEGLU) && (a.epi & EPI_OUT_F32)) return ctx->fail("gemm: GEGLU with fp32 output is not supported");
   if (a.M <= 0 || a.N <= 0) return 0;
   if (ctx->dtype == DT_F16) return launch_gemm<f16>(ctx, a);
   if (ctx->dtype == DT_BF16) return launch_gemm<bf16>(ctx, a);

@@ -36,6 +36,7 @@ struct GemmParams {
   int H, Wd, Cin, Ho, Wo, stride, pad_t, pad_l;
   // temporal geometry (A_TCONV3): m = f*HW + p
   int HW, F;
+  int up_crop;   // A_CONV3X3_UP: rows dropped at top and bottom of the 2x-upsampled image (1: UNet Upsample, 0: VAE Upsample2D)
   int epi;
   int tiles_m, tiles_n;
 };
@@ -135,10 +136,10 @@ gemm_kernel(const GemmParams p) {
         const int yi = a_y[j] + ky, xi = a_x[j] + kx;
         src = (yi >= 0 && yi < p.H && xi >= 0 && xi < p.Wd)
                   ? (const void*)(a_ptr[j] + ((size_t)yi * p.Wd + xi) * p.lda + c0) : p.zero_page;
-      } else {  // A_CONV3X3_UP: conv input U[y][x] = X[(y+1)>>1][x>>1], U is (2H-2) x (2Wd)
+      } else {  // A_CONV3X3_UP: conv input U[y][x] = X[(y+crop)>>1][x>>1], U is (2H-2*crop) x (2Wd)
         const int yu = a_y[j] + ky, xu = a_x[j] + kx;
-        src = (yu >= 0 && yu < 2 * p.H - 2 && xu >= 0 && xu < 2 * p.Wd)
-                  ? (const void*)(a_ptr[j] + ((size_t)((yu + 1) >> 1) * p.Wd + (xu >> 1)) * p.lda + c0) : p.zero_page;
+        src = (yu >= 0 && yu < 2 * p.H - 2 * p.up_crop && xu >= 0 && xu < 2 * p.Wd)
+                  ? (const void*)(a_ptr[j] + ((size_t)((yu + p.up_crop) >> 1) * p.Wd + (xu >> 1)) * p.lda + c0) : p.zero_page;
       }
       // wave-uniform LDS base: chunk q = j*NT + tid -> byte q*16 ; wave base = (j*NT + wave*64)*16
       glds16(src, abuf + (size_t)(j * NT + wave * 64) * 16);
@@ -193,6 +194,37 @@ gemm_kernel(const GemmParams p) {
 
   // ------------------------------------------------------------------ epilogue
   // lane holds, for m = i*32 + (lane&31): n = j*32 + 8*(r>>2) + 4*(lane>>5) + (r&3)
+  if (p.epi & EPI_OUT_F32) {
+    // exact fp32 results straight from the accumulators (attention logits of the VAE, final latent prediction):
+    // 16-B stores of 4 consecutive n per lane; rows differ per lane (not staged: fp32 tiles do not fit the LDS budget)
+    const float* __restrict__ biasf = p.bias;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = m0 + wm * WTM + i * 32 + frow;
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = n0 + wn * WTN + j * 32 + 8 * g + 4 * fhalf;
+          if (m >= p.M || n >= p.N) continue;
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] = acc[i][j][g * 4 + e];
+            if ((p.epi & EPI_BIAS) && n + e < p.N) v[e] += biasf[n + e];
+            if ((p.epi & EPI_RES) && n + e < p.N) v[e] += to_f32<T>(((const T*)p.res)[(size_t)m * p.ldr + n + e]);
+          }
+          float* cp = (float*)p.C + (size_t)m * p.ldc + n;
+          if (n + 4 <= p.N && ((p.ldc & 3) == 0)) {
+            f32x4 o; o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+            *reinterpret_cast<f32x4*>(cp) = o;
+          } else {
+            for (int e = 0; e < 4 && n + e < p.N; ++e) cp[e] = v[e];
+          }
+        }
+    }
+    return;
+  }
   const bool geglu = (p.epi & EPI_GEGLU) != 0;
   constexpr int OUT_TN_MAX = TN;
   const int out_wtn = geglu ? WTN / 2 : WTN;       // output columns per wave
@@ -201,7 +233,6 @@ gemm_kernel(const GemmParams p) {
   const int pitch = WTN * 2 + 8;                    // bytes; (pitch/4) % 4 == 2 -> conflict-free b64 writes
   block_sync();                                     // all MFMA reads of the stages are done
   char* my = smem + wave * (32 * (WTN * 2 + 8));
-  const bool out_f32 = (p.epi & EPI_OUT_F32) != 0;
   const float* __restrict__ bias = p.bias;
 
 #pragma unroll
@@ -266,19 +297,14 @@ gemm_kernel(const GemmParams p) {
           for (int e = 0; e < 8 && n + e < N_out; ++e) v[e] += to_f32<T>(rp[e]);
         }
       }
-      if (out_f32) {
-        float* cp = (float*)p.C + (size_t)m * p.ldc + n;
-        for (int e = 0; e < 8 && n + e < N_out; ++e) cp[e] = v[e];
-      } else {
-        T* cp = (T*)p.C + (size_t)m * p.ldc + n;
-        if (full && ((p.ldc & 7) == 0)) {
-          vec<T, 8> ov;
+      T* cp = (T*)p.C + (size_t)m * p.ldc + n;
+      if (full && ((p.ldc & 7) == 0)) {
+        vec<T, 8> ov;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) ov[e] = from_f32<T>(v[e]);
-          *reinterpret_cast<vec<T, 8>*>(cp) = ov;
-        } else {
-          for (int e = 0; e < 8 && n + e < N_out; ++e) cp[e] = from_f32<T>(v[e]);
-        }
+        for (int e = 0; e < 8; ++e) ov[e] = from_f32<T>(v[e]);
+        *reinterpret_cast<vec<T, 8>*>(cp) = ov;
+      } else {
+        for (int e = 0; e < 8 && n + e < N_out; ++e) cp[e] = from_f32<T>(v[e]);
       }
     }
     block_sync();

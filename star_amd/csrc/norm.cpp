@@ -86,9 +86,10 @@ int op_add(Ctx* ctx, const void* a, const void* b, void* out, long long n) {
   return 0;
 }
 
-int op_stem_im2col(Ctx* ctx, const float* latent, void* out, int Cl, int F, int H, int W) {
+int op_stem_im2col(Ctx* ctx, const float* latent, void* out, int Cl, int F, int H, int W, bool frame_major) {
   if (9 * Cl > 64) return ctx->fail("stem_im2col: at most 7 latent channels");
-  StemIm2colParams p{latent, out, Cl, F, H, W};
+  const long long hw = (long long)H * W;
+  StemIm2colParams p{latent, out, Cl, F, H, W, frame_major ? (long long)Cl * hw : hw, frame_major ? hw : (long long)F * hw};
   const unsigned g = ew_grid((long long)F * H * W * 8);
   if (ctx->dtype == DT_F16) STAR_LAUNCH((stem_im2col_kernel<f16>), dim3(g), dim3(256), (size_t)0, ctx->stream, p);
   else STAR_LAUNCH((stem_im2col_kernel<bf16>), dim3(g), dim3(256), (size_t)0, ctx->stream, p);
@@ -107,6 +108,19 @@ int op_gemv(Ctx* ctx, const float* x, const void* W, const float* b, float* y, i
   dim3 grid((unsigned)((N + 3) / 4)), block(256);
   if (ctx->dtype == DT_F16) STAR_LAUNCH((gemv_kernel<f16>), grid, block, (size_t)0, ctx->stream, p);
   else STAR_LAUNCH((gemv_kernel<bf16>), grid, block, (size_t)0, ctx->stream, p);
+  return 0;
+}
+
+int op_softmax_rows(Ctx* ctx, const float* s, int lds, void* pout, int ldp, int rows, int n, float scale) {
+  SoftmaxParams p{s, pout, rows, n, lds, ldp, scale * 1.4426950408889634f};
+  if (ctx->dtype == DT_F16) STAR_LAUNCH((softmax_rows_kernel<f16>), dim3((unsigned)rows), dim3(256), (size_t)64, ctx->stream, p);
+  else STAR_LAUNCH((softmax_rows_kernel<bf16>), dim3((unsigned)rows), dim3(256), (size_t)64, ctx->stream, p);
+  return 0;
+}
+
+int op_time_conv_out(Ctx* ctx, const float* rows, int ld, float* out, const float* w, const float* b, int F, int HW, int C) {
+  TimeConvOutParams p{rows, out, w, b, F, HW, ld, C};
+  STAR_LAUNCH(time_conv_out_kernel, dim3(ew_grid((long long)F * HW)), dim3(256), (size_t)0, ctx->stream, p);
   return 0;
 }
 

@@ -234,7 +234,7 @@ STAR_GLOBAL void add_kernel(const AddParams p) {
 
 // latent [1, Cl, F, H, W] (fp32) -> im2col rows [F*H*W][64] of the 3x3 pad-1 stem conv: column tap*Cl + c, rest 0
 // (unet_v2v.py:1353 nn.Conv2d(in_dim, dim, 3, padding=1) and :2128 input_hint_block)
-struct StemIm2colParams { const float* x; void* out; int Cl, F, H, W; };
+struct StemIm2colParams { const float* x; void* out; int Cl, F, H, W; long long fs, cs; };  // x[f*fs + c*cs + y*W + x]
 template <class T>
 STAR_GLOBAL void stem_im2col_kernel(const StemIm2colParams p) {
   const long long rows = (long long)p.F * p.H * p.W;
@@ -252,7 +252,7 @@ STAR_GLOBAL void stem_im2col_kernel(const StemIm2colParams p) {
       if (col < 9 * p.Cl) {
         const int tap = col / p.Cl, c = col - tap * p.Cl;
         const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
-        if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) v = p.x[(((size_t)c * p.F + f) * p.H + yy) * p.W + xx];
+        if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) v = p.x[(size_t)f * p.fs + (size_t)c * p.cs + (size_t)yy * p.W + xx];
       }
       o[e] = from_f32<T>(v);
     }
@@ -294,6 +294,56 @@ STAR_GLOBAL void gemv_kernel(const GemvParams p) {
     float r = acc + (p.b ? p.b[n] : 0.f);
     if (p.silu_out) r = silu_f(r);
     p.y[n] = r;
+  }
+}
+
+// ------------------------------------------------------------------ VAE-only kernels
+// row softmax of fp32 logits (scaled) -> T probabilities, zero-filling the padded tail [n, ld)
+// (SVD VAE mid-block attention: one head of 512 channels over all H*W tokens; logits are materialised in fp32)
+struct SoftmaxParams { const float* s; void* p; int rows, n, lds, ldp; float scale_log2e; };
+template <class T>
+STAR_GLOBAL void softmax_rows_kernel(const SoftmaxParams p) {
+  float* red = reinterpret_cast<float*>(dyn_smem());  // [8]
+  const int row = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6, nw = blockDim.x >> 6;
+  const float* __restrict__ s = p.s + (size_t)row * p.lds;
+  float mx = -3.0e38f;
+  for (int i = t; i < p.n; i += blockDim.x) mx = fmaxf(mx, s[i]);
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  block_sync();
+  mx = red[0];
+  for (int w = 1; w < nw; ++w) mx = fmaxf(mx, red[w]);
+  block_sync();
+  const float c = p.scale_log2e, mc = mx * c;
+  float sum = 0.f;
+  for (int i = t; i < p.n; i += blockDim.x) sum += fast_exp2(s[i] * c - mc);
+  sum = wave_sum(sum);
+  if (lane == 0) red[wave] = sum;
+  block_sync();
+  sum = 0.f;
+  for (int w = 0; w < nw; ++w) sum += red[w];
+  const float inv = 1.0f / sum;
+  T* __restrict__ o = (T*)p.p + (size_t)row * p.ldp;
+  for (int i = t; i < p.ldp; i += blockDim.x) o[i] = from_f32<T>(i < p.n ? fast_exp2(s[i] * c - mc) * inv : 0.f);
+}
+
+// time_conv_out (Conv3d 3->3, kernel (3,1,1), zero pad over frames) + rows -> NCHW:
+// rows[f*HW + p][ld] fp32 -> out[f][c][p] fp32  (diffusers TemporalDecoder.time_conv_out)
+struct TimeConvOutParams { const float* rows; float* out; const float* w; const float* b; int F, HW, ld, C; };
+STAR_GLOBAL void time_conv_out_kernel(const TimeConvOutParams p) {
+  const long long total = (long long)p.F * p.HW;
+  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long long)gridDim.x * blockDim.x) {
+    const int f = (int)(q / p.HW); const int px = (int)(q - (long long)f * p.HW);
+    for (int co = 0; co < p.C; ++co) {
+      float acc = p.b[co];
+      for (int tap = 0; tap < 3; ++tap) {
+        const int ff = f + tap - 1;
+        if (ff < 0 || ff >= p.F) continue;
+        const float* r = p.rows + ((size_t)ff * p.HW + px) * p.ld;
+        for (int ci = 0; ci < p.C; ++ci) acc += p.w[(co * p.C + ci) * 3 + tap] * r[ci];
+      }
+      p.out[((size_t)f * p.C + co) * p.HW + px] = acc;
+    }
   }
 }
 

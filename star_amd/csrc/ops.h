@@ -14,6 +14,7 @@ struct GemmArgs {
   int mode = A_PLAIN;
   int H = 0, Wd = 0, Cin = 0, Ho = 0, Wo = 0, stride = 1, pad_t = 1, pad_l = 1;
   int HW = 0, F = 0;
+  int up_crop = 1;
   int epi = 0;
   int force_tile = 0;  // 0 = auto; 1 = 256x256, 2 = 256x320, 3 = 128x128, 4 = 256x128 (tests)
 };
@@ -47,7 +48,9 @@ int op_layer_norm(Ctx* ctx, const void* x, int ldx, void* y, int ldy, const floa
                   int rows, int C, float eps, int mode, const float* gate_w, float* maps, int H, int W);
 int op_concat_add(Ctx* ctx, const void* a, const void* b, const void* c, void* out, int rows, int C1, int C2);
 int op_add(Ctx* ctx, const void* a, const void* b, void* out, long long n);
-int op_stem_im2col(Ctx* ctx, const float* latent, void* out, int Cl, int F, int H, int W);
+int op_stem_im2col(Ctx* ctx, const float* latent, void* out, int Cl, int F, int H, int W, bool frame_major = false);
+int op_softmax_rows(Ctx* ctx, const float* s, int lds, void* pout, int ldp, int rows, int n, float scale);
+int op_time_conv_out(Ctx* ctx, const float* rows, int ld, float* out, const float* w, const float* b, int F, int HW, int C);
 int op_rows_to_latent(Ctx* ctx, const float* rows, float* out, int Cl, int ld, long long ntok);
 int op_gemv(Ctx* ctx, const float* x, const void* W, const float* b, float* y, int N, int K, bool silu_in, bool silu_out);
 int op_cast(Ctx* ctx, const float* x, void* y, long long n);

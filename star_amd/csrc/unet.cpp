@@ -16,134 +16,7 @@ UNetModel::~UNetModel() { for (void* p : owned) rt::dev_free(p); }
 // ------------------------------------------------------------------ weight staging / repacking
 namespace {
 
-struct Builder {
-  Ctx* ctx;
-  std::vector<void*>* owned;
-  std::string err;
-
-  const HostTensor* get(const std::string& name) {
-    auto it = ctx->host_tensors.find(name);
-    if (it == ctx->host_tensors.end()) { if (err.empty()) err = "missing tensor: " + name; return nullptr; }
-    return &it->second;
-  }
-  static uint16_t cvt16(float v, int dtype) {
-    if (dtype == DT_F16) { f16 h = (f16)v; uint16_t u; memcpy(&u, &h, 2); return u; }
-    uint32_t u; memcpy(&u, &v, 4);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
-  }
-  DevW upload_T(const std::vector<float>& v) {
-    std::vector<uint16_t> h(v.size());
-    for (size_t i = 0; i < v.size(); ++i) h[i] = cvt16(v[i], ctx->dtype);
-    DevW d; d.n = (int64_t)v.size();
-    if (rt::dev_malloc(&d.p, h.size() * 2 + 256)) { err = "device OOM uploading weights"; return d; }
-    owned->push_back(d.p);
-    rt::memcpy_h2d(d.p, h.data(), h.size() * 2, ctx->stream);
-    rt::stream_sync(ctx->stream);
-    return d;
-  }
-  DevW upload_f32(const std::vector<float>& v) {
-    DevW d; d.n = (int64_t)v.size();
-    if (rt::dev_malloc(&d.p, v.size() * 4 + 256)) { err = "device OOM uploading weights"; return d; }
-    owned->push_back(d.p);
-    rt::memcpy_h2d(d.p, v.data(), v.size() * 4, ctx->stream);
-    rt::stream_sync(ctx->stream);
-    return d;
-  }
-  NormW norm(const std::string& p) {
-    NormW n;
-    const HostTensor* g = get(p + ".weight"); const HostTensor* b = get(p + ".bias");
-    if (!g || !b) return n;
-    n.C = (int)g->data.size(); n.g = upload_f32(g->data); n.b = upload_f32(b->data);
-    return n;
-  }
-  DevW bias(const std::string& name) {
-    const HostTensor* b = get(name);
-    return b ? upload_f32(b->data) : DevW{};
-  }
-  // nn.Linear / 1x1 conv / Conv1d(k=1): weight [N, K, (1,1)] -> [N][K]
-  LinW linear(const std::string& p, bool has_bias = true) {
-    LinW l;
-    const HostTensor* w = get(p + ".weight");
-    if (!w) return l;
-    l.N = (int)w->shape[0]; l.K = (int)(w->data.size() / (size_t)l.N);
-    l.w = upload_T(w->data);
-    if (has_bias) l.b = bias(p + ".bias");
-    return l;
-  }
-  // Conv2d 3x3 [N, C, 3, 3] -> [N][tap][C] (K = 9C, tap-major), tap = ky*3 + kx
-  LinW conv3x3(const std::string& p) {
-    LinW l;
-    const HostTensor* w = get(p + ".weight");
-    if (!w) return l;
-    const int N = (int)w->shape[0], C = (int)w->shape[1];
-    std::vector<float> r((size_t)N * 9 * C);
-    for (int n = 0; n < N; ++n) for (int c = 0; c < C; ++c) for (int t = 0; t < 9; ++t)
-      r[((size_t)n * 9 + t) * C + c] = w->data[((size_t)n * C + c) * 9 + t];
-    l.N = N; l.K = 9 * C; l.w = upload_T(r); l.b = bias(p + ".bias");
-    return l;
-  }
-  // stem-like Conv2d 3x3 with tiny C (4): [N, C, 3, 3] -> [N][64] columns tap*C + c, zero padded (pairs with stem_im2col)
-  LinW conv3x3_im2col64(const std::string& p) {
-    LinW l;
-    const HostTensor* w = get(p + ".weight");
-    if (!w) return l;
-    const int N = (int)w->shape[0], C = (int)w->shape[1];
-    std::vector<float> r((size_t)N * 64, 0.f);
-    for (int n = 0; n < N; ++n) for (int c = 0; c < C; ++c) for (int t = 0; t < 9; ++t)
-      r[(size_t)n * 64 + t * C + c] = w->data[((size_t)n * C + c) * 9 + t];
-    l.N = N; l.K = 64; l.w = upload_T(r); l.b = bias(p + ".bias");
-    return l;
-  }
-  // Conv3d (3,1,1) [N, C, 3, 1, 1] -> [N][tap][C]
-  LinW tconv(const std::string& p) {
-    LinW l;
-    const HostTensor* w = get(p + ".weight");
-    if (!w) return l;
-    const int N = (int)w->shape[0], C = (int)w->shape[1];
-    std::vector<float> r((size_t)N * 3 * C);
-    for (int n = 0; n < N; ++n) for (int c = 0; c < C; ++c) for (int t = 0; t < 3; ++t)
-      r[((size_t)n * 3 + t) * C + c] = w->data[((size_t)n * C + c) * 3 + t];
-    l.N = N; l.K = 3 * C; l.w = upload_T(r); l.b = bias(p + ".bias");
-    return l;
-  }
-  // row-concatenate several [Ni, K] matrices (fused q|k|v)
-  LinW fused(const std::vector<std::string>& names) {
-    LinW l;
-    std::vector<float> r;
-    for (auto& nm : names) {
-      const HostTensor* w = get(nm + ".weight");
-      if (!w) return l;
-      l.K = (int)(w->data.size() / (size_t)w->shape[0]);
-      l.N += (int)w->shape[0];
-      r.insert(r.end(), w->data.begin(), w->data.end());
-    }
-    l.w = upload_T(r);
-    return l;
-  }
-  // GEGLU projection [2H, K] (value rows, gate rows) -> alternating 32-row (value, gate) blocks
-  LinW geglu(const std::string& p) {
-    LinW l;
-    const HostTensor* w = get(p + ".weight"); const HostTensor* b = get(p + ".bias");
-    if (!w || !b) return l;
-    const int N2 = (int)w->shape[0], K = (int)w->shape[1], Hh = N2 / 2;
-    std::vector<float> r((size_t)N2 * K), rb(N2);
-    for (int blk = 0; blk < Hh / 32; ++blk)
-      for (int half = 0; half < 2; ++half)
-        for (int i = 0; i < 32; ++i) {
-          const int src = half * Hh + blk * 32 + i, dst = blk * 64 + half * 32 + i;
-          memcpy(&r[(size_t)dst * K], &w->data[(size_t)src * K], (size_t)K * 4);
-          rb[dst] = b->data[src];
-        }
-    l.N = N2; l.K = K; l.w = upload_T(r); l.b = upload_f32(rb);
-    return l;
-  }
-  DevW raw_f32(const std::string& name) {
-    const HostTensor* t = get(name);
-    return t ? upload_f32(t->data) : DevW{};
-  }
-
+struct UBuilder : Builder {
   ResW res(const std::string& p) {
     ResW r;
     r.gn1 = norm(p + ".in_layers.0");
@@ -198,59 +71,7 @@ struct Builder {
 };
 
 // ------------------------------------------------------------------ forward helpers
-struct Act {          // an activation tensor: rows = F*H*W tokens; the buffer returns to the pool with its last owner
-  std::shared_ptr<Buf> buf; int C = 0, H = 0, W = 0;
-  void* p() const { return buf ? buf->p : nullptr; }
-  void drop() { buf.reset(); }
-};
-
-struct Fwd {
-  Ctx* ctx;
-  int F = 0;
-  size_t es = 2;
-  float* emb = nullptr;        // fp32 [E] (device) time embedding of the running net
-  const void* context = nullptr;  // T [77][ctx_dim]
-  int ctx_dim = 0, embed_dim = 0;
-  int rc = 0;
-
-  Act make(int C, int H, int W) {
-    Act a; a.C = C; a.H = H; a.W = W;
-    a.buf = std::make_shared<Buf>(ctx, (size_t)F * H * W * C * es);
-    if (!a.buf->p) { rc = ctx->fail("out of device memory (activations)"); }
-    return a;
-  }
-  int rows(const Act& a) const { return F * a.H * a.W; }
-  void ok(int r) { if (r && !rc) rc = r; }
-
-  // y = x W^T (+b) (+res)
-  void gemm(const void* A, int lda, int M, const LinW& w, void* C, int ldc, const void* res = nullptr, int ldr = 0, int extra_epi = 0,
-            const float* bias_override = nullptr) {
-    GemmArgs g;
-    g.A = A; g.W = w.w.p; g.C = C; g.M = M; g.N = w.N; g.K = w.K; g.lda = lda; g.ldc = ldc;
-    g.bias = bias_override ? bias_override : (const float*)w.b.p;
-    g.res = res; g.ldr = ldr;
-    g.epi = (g.bias ? EPI_BIAS : 0) | (res ? EPI_RES : 0) | extra_epi;
-    ok(op_gemm(ctx, g));
-  }
-  void conv3x3(const Act& x, const LinW& w, Act& y, int mode, int stride, int pad_t, int pad_l, const void* res, const float* bias_override = nullptr,
-               int extra_epi = 0, void* out_override = nullptr, int ldc_override = 0) {
-    GemmArgs g;
-    g.A = x.p(); g.W = w.w.p; g.C = out_override ? out_override : y.p();
-    g.M = F * y.H * y.W; g.N = w.N; g.K = w.K; g.lda = x.C; g.ldc = ldc_override ? ldc_override : y.C;
-    g.mode = mode; g.H = x.H; g.Wd = x.W; g.Cin = x.C; g.Ho = y.H; g.Wo = y.W; g.stride = stride; g.pad_t = pad_t; g.pad_l = pad_l;
-    g.bias = bias_override ? bias_override : (const float*)w.b.p;
-    g.res = res; g.ldr = y.C;
-    g.epi = (g.bias ? EPI_BIAS : 0) | (res ? EPI_RES : 0) | extra_epi;
-    ok(op_gemm(ctx, g));
-  }
-  void gn(const Act& x, const NormW& n, Act& y, bool whole_chunk, float eps, bool silu) {
-    const int rps = whole_chunk ? F * x.H * x.W : x.H * x.W;
-    ok(op_group_norm(ctx, x.p(), x.C, y.p(), y.C, (const float*)n.g.p, (const float*)n.b.p, rows(x), x.C, rps, eps, silu));
-  }
-  void ln(const void* x, void* y, int rws, int C, const NormW& n, int mode = LN_PLAIN, const float* gw = nullptr, float* maps = nullptr, int H = 0, int W = 0) {
-    ok(op_layer_norm(ctx, x, C, y, C, (const float*)n.g.p, (const float*)n.b.p, rws, C, 1e-5f, mode, gw, maps, H, W));
-  }
-
+struct Fwd : Runner {
   // ResBlock._forward + TemporalConvBlock_v2 (unet_v2v.py:666-692, 1266-1277)
   Act res_block(const ResW& r, Act x) {
     const int R = rows(x);
@@ -425,7 +246,7 @@ static void host_sinusoidal(long long t, int dim, std::vector<float>& out) {   /
   }
 }
 
-static int build_net(Builder& b, const UNetCfg& cfg, bool control, Net& net) {
+static int build_net(UBuilder& b, const UNetCfg& cfg, bool control, Net& net) {
   const std::string P = control ? "VideoControlNet." : "";
   net.time0 = b.linear(P + "time_embed.0");
   net.time2 = b.linear(P + "time_embed.2");
@@ -507,7 +328,7 @@ static int build_net(Builder& b, const UNetCfg& cfg, bool control, Net& net) {
 int unet_build(Ctx* ctx, const UNetCfg& cfg) {
   auto model = std::make_shared<UNetModel>();
   model->cfg = cfg;
-  Builder b{ctx, &model->owned, ""};
+  UBuilder b{{ctx, &model->owned, ""}};
   if (build_net(b, cfg, false, model->main) || build_net(b, cfg, true, model->control)) return ctx->fail("unet_build: " + b.err);
   if (!b.err.empty()) return ctx->fail("unet_build: " + b.err);
   ctx->unet = model;
@@ -619,7 +440,7 @@ int unet_forward(Ctx* ctx, const float* xt, long long t, const float* y, const f
 int module_run(Ctx* ctx, int kind, const char* prefix, int cin, int cout, int heads, int embed_dim, int context_dim,
                const void* x, const float* emb, const float* context, void* out, int F, int H, int W) {
   UNetModel tmp;
-  Builder b{ctx, &tmp.owned, ""};
+  UBuilder b{{ctx, &tmp.owned, ""}};
   Fwd f; f.ctx = ctx; f.F = F; f.es = ctx->esize(); f.ctx_dim = context_dim; f.embed_dim = embed_dim;
   f.emb = const_cast<float*>(emb);
   Buf ctxT;

@@ -1,6 +1,6 @@
 // unet.h -- host-side model of ControlledV2VUNet + VideoControlNet for the C++ graph executor.
 #pragma once
-#include "ops.h"
+#include "graph.h"
 #include <string>
 #include <vector>
 
@@ -14,13 +14,6 @@ struct UNetCfg {
   int attn_levels = 3;   // levels 0..attn_levels-1 carry transformers (attn_scales 1, 1/2, 1/4)
   int embed_dim() const { return dim * 4; }
 };
-
-struct DevW {            // a device-resident parameter tensor
-  void* p = nullptr;
-  int64_t n = 0;
-};
-struct LinW { DevW w; DevW b; int N = 0, K = 0; };   // w: T [N][K]; b: fp32 [N] (may be empty)
-struct NormW { DevW g, b; int C = 0; };               // fp32
 
 struct ResW {
   int cin = 0, cout = 0;

@@ -60,7 +60,7 @@ class GemmDesc(ctypes.Structure):
         ("H", ctypes.c_int32), ("Wd", ctypes.c_int32), ("Cin", ctypes.c_int32),
         ("Ho", ctypes.c_int32), ("Wo", ctypes.c_int32), ("stride", ctypes.c_int32),
         ("pad_t", ctypes.c_int32), ("pad_l", ctypes.c_int32),
-        ("HW", ctypes.c_int32), ("F", ctypes.c_int32),
+        ("HW", ctypes.c_int32), ("F", ctypes.c_int32), ("up_crop", ctypes.c_int32),
         ("epi", ctypes.c_int32), ("force_tile", ctypes.c_int32),
     ]
 
@@ -176,7 +176,7 @@ class Context:
 
     # ------------------------------------------------------------------ kernels
     def gemm(self, A, W, bias=None, res=None, out=None, *, mode=A_PLAIN, M=None, conv=None, temporal=None,
-             geglu=False, out_f32=False, force_tile=0):
+             geglu=False, out_f32=False, force_tile=0, up_crop=1):
         """out[M, N] = epilogue(A' @ W^T).  A: [rows, lda] activations (channels-last tokens);
         W: [N, K]; conv=(NB,H,Wd,Cin,Ho,Wo,stride,pad_t,pad_l); temporal=(F,HW,Cin)."""
         self._chk_tensor(A, self.dtype); self._chk_tensor(W, self.dtype)
@@ -185,6 +185,7 @@ class Context:
         d = GemmDesc()
         d.mode = mode
         d.stride, d.pad_t, d.pad_l = 1, 1, 1
+        d.up_crop = up_crop
         if mode == A_PLAIN:
             M = A.shape[0] if M is None else M
         elif mode in (A_CONV3X3, A_CONV3X3_UP):
