@@ -1,0 +1,186 @@
+"""bench.py -- upscaled frames/s of the STAR hot path on MI355X (BASELINE.json metric).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]           (N > 1: launched by torch.distributed.run)
+
+One "step" = one full `VideoToVideo_sr.test()` on a synthetic 32-frame 240x426 clip -> 4x (BASELINE config[1]):
+bilinear upsample + pad to 976x1728, VAE encode of 32 frames, 50 DPM-Solver++ evaluations x 2 denoiser forwards
+(CFG), VAE decode in 3-frame groups; the LR clip is already resident in HBM when the timed region starts.
+N GPUs = N independent clips, one per rank (weak scaling), with an RCCL all-gather of the decoded frames (C1).
+Random-init weights of the full architecture (2.04 B-parameter UNet+ControlNet, 97.7 M-parameter SVD VAE) and
+synthetic data: no checkpoint or dataset is reachable offline.
+
+Besides the headline line, the JSON carries `roofline` (the spatial self-attention kernel, timed live with HIP
+events on the launch stream) and `cpu_baseline` (the CPU oracle timed on this box's host cores on a bounded
+sample, extrapolated by FLOP ratio -- never presented as measured end-to-end).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic FLOPs (2 per MAC; matmul + conv + attention), SURVEY.md section 8(d) / BASELINE.md section 3
+UNET_FWD_TFLOP_CFG2 = 572.3         # one UNet+ControlNet forward, 32 f, latent 122x216
+VAE_TFLOP_PER_FRAME = 8.4 + 20.8    # encode + decode at 976x1728 (estimate)
+PEAK_BF16_MFMA = 2.5e15             # dense, MI355X_MICROARCH.md
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=0)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
+    ap.add_argument("--frames", type=int, default=32)
+    ap.add_argument("--height", type=int, default=240)
+    ap.add_argument("--width", type=int, default=426)
+    ap.add_argument("--denoise-steps", type=int, default=50)
+    ap.add_argument("--solver-mode", default="normal", choices=["normal", "fast"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--small", action="store_true", help="reduced-width smoke configuration (NOT the metric)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.set_grad_enabled(False)
+    dtype = {"bf16": torch.bfloat16, "f16": torch.float16}[args.dtype]
+    dev = torch.device("cuda", local_rank)
+
+    from star_amd.topology import SMALL_TEST_CONFIG, UNetConfig, random_state_dict
+    from star_amd.vae_topology import SMALL_VAE_CONFIG, VaeConfig, random_vae_state_dict
+    from star_amd.video_to_video_model import VideoToVideo_sr
+    ucfg = SMALL_TEST_CONFIG if args.small else UNetConfig()
+    vcfg = SMALL_VAE_CONFIG if args.small else VaeConfig()
+
+    t0 = time.time()
+    sd = random_state_dict(ucfg, seed=0)
+    t_weights = time.time() - t0
+
+    # ---------------- CPU baseline: the oracle (a port of the reference arithmetic) on the host cores, bounded sample
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_baseline = run_cpu_baseline(sd, ucfg, args)
+
+    gneg = torch.Generator().manual_seed(668)
+    opt = dict(state_dict=sd, vae_state_dict=random_vae_state_dict(vcfg, seed=0), unet_config=ucfg, vae_config=vcfg, dtype=dtype,
+               negative_y=torch.randn(1, 77, ucfg.context_dim, generator=gneg))
+    t0 = time.time()
+    model = VideoToVideo_sr(opt, device=dev)
+    del sd, opt
+    t_load = time.time() - t0
+
+    # synthetic LR clip + text embedding (seeds: SURVEY.md section 8d), resident on the device
+    g = torch.Generator().manual_seed(666 + rank)
+    video = (torch.randn(args.frames, 3, args.height, args.width, generator=g) * 0.5).clamp(-1, 1).to(dev)
+    y = torch.randn(1, 77, ucfg.context_dim, generator=torch.Generator().manual_seed(667)).to(dev)
+    data = {"video_data": video, "y": y, "target_res": (args.height * 4, args.width * 4)}
+
+    def step():
+        torch.manual_seed(666 + rank)
+        out = model.test(data, total_noise_levels=900, steps=args.denoise_steps, solver_mode=args.solver_mode,
+                         guide_scale=7.5, max_chunk_len=max(32, args.frames), return_device=True)
+        if world > 1:
+            from star_amd.parallel import gather_frames
+            out = gather_frames(out)
+        return out
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    uctx, vctx = model.generator.ctx, model.vae.ctx
+    barrier()
+    uctx.profile_begin(); vctx.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof_u, prof_v = uctx.profile_end(), vctx.profile_end()
+    if world > 1:
+        import torch.distributed as dist
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    final = out[0] if isinstance(out, list) else out
+    finite = bool(torch.isfinite(final).all())
+
+    if rank == 0:
+        frames_total = args.frames * world * args.steps
+        evals = 14 if args.solver_mode == "fast" else args.denoise_steps
+        a = prof_u["attn_self"]
+        l0_flops = a["max_flops"]                       # the largest launches = the L0 layers (N = H*W of the padded latent)
+        roof = {"bound": "mfma", "kernel": "flash_attn_kernel (spatial self-attention, d=64)", "unit": "TFLOP/s",
+                "achieved": (l0_flops / (a["max_flops_ms"] * 1e-3) / 1e12) if a["max_flops_ms"] else None,
+                "peak": PEAK_BF16_MFMA / 1e12, "traffic": None,
+                "algorithmic_flops_per_launch": l0_flops, "avg_launch_ms": a["max_flops_ms"],
+                "all_self_attn_launches": {"launches": a["launches"], "ms": a["ms"], "TFLOP/s": a["flops"] / max(a["ms"], 1e-9) / 1e9}}
+        roof["frac"] = roof["achieved"] / roof["peak"] if roof["achieved"] else None
+        breakdown = {k: {"ms": round(v["ms"], 1), "launches": v["launches"],
+                         "TFLOP/s": round(v["flops"] / v["ms"] / 1e9, 1) if v["ms"] and v["flops"] else None,
+                         "GB/s": round(v["bytes"] / v["ms"] / 1e6, 1) if v["ms"] else None} for k, v in prof_u.items()}
+        line = {
+            "metric": "upscaled frames/sec (4x, 32f 240x426 chunk)", "value": frames_total / elapsed, "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"I2VGen-XL STAR light_deg path, {args.frames}f {args.height}x{args.width} -> 4x "
+                                   f"({args.height * 4}x{args.width * 4}, padded latent), solver_mode={args.solver_mode}, "
+                                   f"{evals} DPM++(2M)SDE evals x 2 CFG forwards, VAE enc 1f/call + dec 3f/group, "
+                                   "random-init weights" + (" [REDUCED-WIDTH SMOKE CONFIG]" if args.small else ""),
+                       "frames_per_gpu": args.frames, "evals": evals, "parallelism": f"chunk-replicas x{world} + RCCL all-gather of frames"},
+            "roofline": roof, "cpu_baseline": cpu_baseline,
+            "unet_kernel_ms": breakdown, "vae_kernel_ms": {k: round(v["ms"], 1) for k, v in prof_v.items()},
+            "setup_s": {"weights": round(t_weights, 1), "load": round(t_load, 1)},
+            "algorithmic_pflop_per_step": (2 * evals * UNET_FWD_TFLOP_CFG2 + args.frames * VAE_TFLOP_PER_FRAME) / 1e3 if not args.small else None,
+            "output_finite": finite, "hbm_pool_gb": {"unet": round(uctx.lib.pool_peak_bytes(uctx.h) / 2 ** 30, 1), "vae": round(vctx.lib.pool_peak_bytes(vctx.h) / 2 ** 30, 1)},
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+def run_cpu_baseline(sd, ucfg, args):
+    """Time the CPU oracle (oracle/unet_oracle.py: a PyTorch fp32 port of the reference forward) on all host cores on a
+    bounded sample -- one UNet+ControlNet forward at f=8, latent 26x24 -- and extrapolate to the benchmark workload by
+    the FLOP ratio (the full workload is ~58 PFLOP: tens of hours on a CPU)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import unet_oracle as O
+    from make_golden import unet_inputs
+    from torch.utils.flop_counter import FlopCounterMode
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    f, h, w = 8, 26, 24
+    x, t, y, hint = unet_inputs(ucfg, f, h, w, 7)
+    O.unet_forward(sd, ucfg, x[:, :, :1, :10, :8].contiguous(), t, y, hint[:, :, :1, :10, :8].contiguous())   # warm the thread pools
+    with FlopCounterMode(display=False) as fc:
+        t0 = time.perf_counter()
+        O.unet_forward(sd, ucfg, x, t, y, hint)
+        secs = time.perf_counter() - t0
+    flops = float(fc.get_total_flops())
+    cpu_flops = flops / secs
+    evals = 14 if args.solver_mode == "fast" else args.denoise_steps
+    total = (2 * evals * UNET_FWD_TFLOP_CFG2 + args.frames * VAE_TFLOP_PER_FRAME) * 1e12
+    return {"value": args.frames / (total / cpu_flops), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"one UNet+ControlNet forward of the fp32 CPU oracle at f={f}, latent {h}x{w} ({flops / 1e12:.2f} TFLOP in {secs:.1f} s = "
+                      f"{cpu_flops / 1e9:.0f} GFLOP/s); frames/s EXTRAPOLATED by FLOP ratio to the {total / 1e15:.1f} PFLOP workload",
+            "measured_gflops": cpu_flops / 1e9, "sample_seconds": secs}
+
+
+if __name__ == "__main__":
+    main()

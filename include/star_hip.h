@@ -131,6 +131,14 @@ int star_vae_encode(star_ctx* ctx, const float* x, float* moments, int32_t n, in
 int star_vae_decode(star_ctx* ctx, const float* z, float* out, int32_t n, int32_t h, int32_t w);
 int star_softmax_rows(star_ctx* ctx, const float* s, int32_t lds, void* p, int32_t ldp, int32_t rows, int32_t n, float scale);
 
+/* ---- live per-kernel-family timing (HIP events on the launch stream; used by bench.py's roofline leg) --------- */
+enum { STAR_PK_ATTN_SELF = 0, STAR_PK_ATTN_CROSS, STAR_PK_TATTN, STAR_PK_GEMM, STAR_PK_CONV, STAR_PK_TCONV, STAR_PK_GN,
+       STAR_PK_LN, STAR_PK_MISC, STAR_PK_COUNT };
+typedef struct star_prof_entry { double ms; double flops; double bytes; double max_flops; double max_flops_ms; int64_t launches; } star_prof_entry;
+int star_profile_begin(star_ctx* ctx);
+/* synchronises, fills out[STAR_PK_COUNT], stops profiling */
+int star_profile_end(star_ctx* ctx, star_prof_entry* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -155,4 +155,27 @@ int star_softmax_rows(star_ctx* h, const float* s, int32_t lds, void* p, int32_t
   return op_softmax_rows(&h->c, s, lds, p, ldp, rows, n, scale);
 }
 
+
+int star_profile_begin(star_ctx* h) {
+  for (auto& r : h->c.prof) { rt::event_destroy(r.e0); rt::event_destroy(r.e1); }
+  h->c.prof.clear();
+  h->c.profiling = true;
+  return 0;
+}
+int star_profile_end(star_ctx* h, star_prof_entry* out) {
+  rt::stream_sync(h->c.stream);
+  for (int k = 0; k < PK_COUNT; ++k) out[k] = star_prof_entry{0, 0, 0, 0, 0, 0};
+  for (auto& r : h->c.prof) {
+    const double ms = rt::event_elapsed_ms(r.e0, r.e1);
+    star_prof_entry& e = out[r.kind];
+    e.ms += ms; e.flops += r.flops; e.bytes += r.bytes; e.launches += 1;
+    if (r.flops > e.max_flops) { e.max_flops = r.flops; e.max_flops_ms = ms; }
+    else if (r.flops == e.max_flops && r.flops > 0) { e.max_flops_ms = 0.5 * (e.max_flops_ms + ms); }
+    rt::event_destroy(r.e0); rt::event_destroy(r.e1);
+  }
+  h->c.prof.clear();
+  h->c.profiling = false;
+  return 0;
+}
+
 }  // extern "C"

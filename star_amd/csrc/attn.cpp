@@ -22,6 +22,8 @@ static int launch_flash(Ctx* ctx, const AttnArgs& a) {
 int op_flash_attn(Ctx* ctx, const AttnArgs& a) {
   if (a.Nq <= 0 || a.Nk <= 0 || a.batch * a.heads <= 0) return 0;
   if ((a.ldq | a.ldk | a.ldv | a.ldo) & 7) return ctx->fail("flash_attn: row strides must be multiples of 8 elements");
+  ProfScope ps(ctx, a.bsk == 0 && a.batch > 1 ? PK_ATTN_CROSS : PK_ATTN_SELF, 4.0 * a.batch * a.heads * (double)a.Nq * a.Nk * 64.0,
+               2.0 * a.batch * a.heads * 64.0 * (2.0 * a.Nq + 2.0 * (a.bsk == 0 ? a.Nk / (double)a.batch : a.Nk)));
   if (ctx->dtype == DT_F16) return launch_flash<f16>(ctx, a);
   if (ctx->dtype == DT_BF16) return launch_flash<bf16>(ctx, a);
   return ctx->fail("flash_attn: unsupported dtype");
@@ -45,6 +47,7 @@ int op_temporal_attn(Ctx* ctx, const TAttnArgs& a) {
   if (a.F <= 0 || a.HW <= 0) return 0;
   if (a.F > 64) return ctx->fail("temporal_attn: at most 64 frames per chunk");
   if ((a.ldq | a.ldk | a.ldv | a.ldo) & 7) return ctx->fail("temporal_attn: row strides must be multiples of 8 elements");
+  ProfScope ps(ctx, PK_TATTN, 4.0 * a.HW * a.heads * (double)a.F * a.F * 64.0, 2.0 * 4.0 * a.F * (double)a.HW * a.heads * 64.0);
   if (ctx->dtype == DT_F16) return launch_tattn<f16>(ctx, a);
   if (ctx->dtype == DT_BF16) return launch_tattn<bf16>(ctx, a);
   return ctx->fail("temporal_attn: unsupported dtype");

@@ -94,6 +94,10 @@ struct HostTensor {
 struct UNetModel;
 struct VaeModel;
 
+// per-kernel-family timing with HIP events on the launch stream (bench.py roofline leg)
+enum ProfKind : int { PK_ATTN_SELF = 0, PK_ATTN_CROSS, PK_TATTN, PK_GEMM, PK_CONV, PK_TCONV, PK_GN, PK_LN, PK_MISC, PK_COUNT };
+struct ProfRec { int kind; double flops; double bytes; void* e0; void* e1; };
+
 struct Ctx {
   int device = 0;
   int dtype = DT_F16;
@@ -104,6 +108,8 @@ struct Ctx {
   std::unordered_map<std::string, HostTensor> host_tensors;  // staged by star_load_tensor
   std::shared_ptr<UNetModel> unet;   // shared_ptr: deleter bound where the type is complete
   std::shared_ptr<VaeModel> vae;
+  bool profiling = false;
+  std::vector<ProfRec> prof;
   int fail(const std::string& m) { err = m; return 1; }
   size_t esize() const { return dtype == DT_F32 ? 4 : 2; }
 };

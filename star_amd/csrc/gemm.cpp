@@ -51,6 +51,10 @@ int op_gemm(Ctx* ctx, const GemmArgs& a) {
   if ((a.epi & EPI_GEGLU) && (a.N % 64 != 0)) return ctx->fail("gemm: GEGLU needs N % 64 == 0");
   if ((a.epi & EPI_GEGLU) && (a.epi & EPI_OUT_F32)) return ctx->fail("gemm: GEGLU with fp32 output is not supported");
   if (a.M <= 0 || a.N <= 0) return 0;
+  const double taps = a.mode == A_PLAIN ? 1.0 : 1.0;
+  (void)taps;
+  ProfScope ps(ctx, a.mode == A_PLAIN ? PK_GEMM : (a.mode == A_TCONV3 ? PK_TCONV : PK_CONV), 2.0 * a.M * (double)a.N * a.K,
+               ((double)a.M * (a.mode == A_PLAIN ? a.K : a.Cin) + (double)a.M * ((a.epi & EPI_GEGLU) ? a.N / 2 : a.N)) * 2.0);
   if (ctx->dtype == DT_F16) return launch_gemm<f16>(ctx, a);
   if (ctx->dtype == DT_BF16) return launch_gemm<bf16>(ctx, a);
   return ctx->fail("gemm: unsupported dtype");

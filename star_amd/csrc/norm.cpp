@@ -41,6 +41,7 @@ int op_group_norm(Ctx* ctx, const void* x, int ldx, void* y, int ldy, const floa
   if (rows % rows_per_stat) return ctx->fail("group_norm: rows not a multiple of rows_per_stat");
   if ((ldx | ldy) & 7) return ctx->fail("group_norm: row strides must be multiples of 8");
   if (C / 8 > 1024) return ctx->fail("group_norm: C too large");
+  ProfScope ps(ctx, PK_GN, 0.0, 3.0 * rows * (double)C * 2.0);
   if (ctx->dtype == DT_F16) return gn_t<f16>(ctx, x, ldx, y, ldy, gamma, beta, rows, C, rows_per_stat, eps, silu);
   return gn_t<bf16>(ctx, x, ldx, y, ldy, gamma, beta, rows, C, rows_per_stat, eps, silu);
 }
@@ -63,12 +64,14 @@ int op_layer_norm(Ctx* ctx, const void* x, int ldx, void* y, int ldy, const floa
   if (C % 8) return ctx->fail("layer_norm: C must be a multiple of 8");
   if ((ldx | ldy) & 7) return ctx->fail("layer_norm: row strides must be multiples of 8");
   if (rows <= 0) return 0;
+  ProfScope ps(ctx, PK_LN, 0.0, (mode == LN_STATS_ONLY ? 1.0 : 2.0) * rows * (double)C * 2.0);
   LnParams p{x, y, gamma, beta, gate_w, maps, ldx, ldy, C, rows, H, W, eps, mode};
   if (ctx->dtype == DT_F16) return ln_t<f16>(ctx, p);
   return ln_t<bf16>(ctx, p);
 }
 
 int op_concat_add(Ctx* ctx, const void* a, const void* b, const void* c, void* out, int rows, int C1, int C2) {
+  ProfScope ps(ctx, PK_MISC, 0.0, 2.0 * rows * (double)(C1 + C2 + (c ? C2 : 0)) * 2.0);
   if ((C1 | C2) & 7) return ctx->fail("concat_add: channel counts must be multiples of 8");
   ConcatParams p{a, b, c, out, C1, C2, rows};
   const unsigned g = ew_grid((long long)rows * ((C1 + C2) / 8));
@@ -78,6 +81,7 @@ int op_concat_add(Ctx* ctx, const void* a, const void* b, const void* c, void* o
 }
 
 int op_add(Ctx* ctx, const void* a, const void* b, void* out, long long n) {
+  ProfScope ps(ctx, PK_MISC, 0.0, 3.0 * n * 2.0);
   if (n & 7) return ctx->fail("add: n must be a multiple of 8");
   AddParams p{a, b, out, n / 8};
   const unsigned g = ew_grid(n / 8);
@@ -112,6 +116,7 @@ int op_gemv(Ctx* ctx, const float* x, const void* W, const float* b, float* y, i
 }
 
 int op_softmax_rows(Ctx* ctx, const float* s, int lds, void* pout, int ldp, int rows, int n, float scale) {
+  ProfScope ps(ctx, PK_MISC, 0.0, (double)rows * n * 10.0);
   SoftmaxParams p{s, pout, rows, n, lds, ldp, scale * 1.4426950408889634f};
   if (ctx->dtype == DT_F16) STAR_LAUNCH((softmax_rows_kernel<f16>), dim3((unsigned)rows), dim3(256), (size_t)64, ctx->stream, p);
   else STAR_LAUNCH((softmax_rows_kernel<bf16>), dim3((unsigned)rows), dim3(256), (size_t)64, ctx->stream, p);

@@ -6,6 +6,18 @@
 
 namespace star {
 
+// RAII: brackets one kernel launch with HIP events when ctx->profiling is on
+struct ProfScope {
+  Ctx* ctx; int idx = -1;
+  ProfScope(Ctx* c, int kind, double flops, double bytes) : ctx(c) {
+    if (!c->profiling) return;
+    ProfRec r{kind, flops, bytes, rt::event_record(c->stream), nullptr};
+    c->prof.push_back(r);
+    idx = (int)c->prof.size() - 1;
+  }
+  ~ProfScope() { if (idx >= 0) ctx->prof[idx].e1 = rt::event_record(ctx->stream); }
+};
+
 struct GemmArgs {
   const void* A = nullptr; const void* W = nullptr; void* C = nullptr;
   const float* bias = nullptr; const void* res = nullptr;

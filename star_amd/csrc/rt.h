@@ -19,6 +19,9 @@ inline int set_device(int) { return 0; }
 inline int device_count() { return 1; }
 inline const char* last_error_string() { return "hostemu"; }
 inline int peek_error() { return 0; }
+inline void* event_record(hipStream_t) { return nullptr; }
+inline float event_elapsed_ms(void*, void*) { return 0.f; }
+inline void event_destroy(void*) {}
 #else
 inline int dev_malloc(void** p, size_t bytes) { return hipMalloc(p, bytes ? bytes : 256) == hipSuccess ? 0 : 1; }
 inline void dev_free(void* p) { (void)hipFree(p); }
@@ -31,6 +34,9 @@ inline int set_device(int d) { return hipSetDevice(d) != hipSuccess; }
 inline int device_count() { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 inline const char* last_error_string() { return hipGetErrorString(hipGetLastError()); }
 inline int peek_error() { return hipPeekAtLastError() != hipSuccess; }
+inline void* event_record(hipStream_t s) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; (void)hipEventRecord(e, s); return (void*)e; }
+inline float event_elapsed_ms(void* a, void* b) { float ms = 0.f; if (a && b) { (void)hipEventSynchronize((hipEvent_t)b); (void)hipEventElapsedTime(&ms, (hipEvent_t)a, (hipEvent_t)b); } return ms; }
+inline void event_destroy(void* e) { if (e) (void)hipEventDestroy((hipEvent_t)e); }
 #endif
 
 }}  // namespace star::rt

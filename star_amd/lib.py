@@ -46,6 +46,14 @@ class TAttnDesc(ctypes.Structure):
     ]
 
 
+PROF_KINDS = ["attn_self", "attn_cross", "temporal_attn", "gemm", "conv3x3", "tconv", "group_norm", "layer_norm", "misc"]
+
+
+class ProfEntry(ctypes.Structure):
+    _fields_ = [("ms", ctypes.c_double), ("flops", ctypes.c_double), ("bytes", ctypes.c_double), ("max_flops", ctypes.c_double),
+                ("max_flops_ms", ctypes.c_double), ("launches", ctypes.c_int64)]
+
+
 class StarError(RuntimeError):
     pass
 
@@ -104,6 +112,8 @@ class Library:
         self.rows_to_latent = _sig(c, "star_rows_to_latent", i32, vp, vp, vp, i32, i32, i64)
         self.gemv = _sig(c, "star_gemv", i32, vp, vp, vp, vp, vp, i32, i32, i32, i32)
         self.cast = _sig(c, "star_cast", i32, vp, vp, vp, i64)
+        self.profile_begin = _sig(c, "star_profile_begin", i32, vp)
+        self.profile_end = _sig(c, "star_profile_end", i32, vp, ctypes.POINTER(ProfEntry))
 
 
 _default_library = None
@@ -170,6 +180,16 @@ class Context:
     def use_current_stream(self):
         if not self.lib.is_hostemu:
             self.lib.set_stream(self.h, ctypes.c_void_p(torch.cuda.current_stream(self.device_index).cuda_stream))
+
+    def profile_begin(self):
+        self._check(self.lib.profile_begin(self.h), "profile_begin")
+
+    def profile_end(self):
+        """-> {family: {ms, flops, bytes, launches, max_flops, max_flops_ms}} measured with HIP events on the launch stream."""
+        arr = (ProfEntry * len(PROF_KINDS))()
+        self._check(self.lib.profile_end(self.h, arr), "profile_end")
+        return {k: {"ms": arr[i].ms, "flops": arr[i].flops, "bytes": arr[i].bytes, "launches": arr[i].launches,
+                    "max_flops": arr[i].max_flops, "max_flops_ms": arr[i].max_flops_ms} for i, k in enumerate(PROF_KINDS)}
 
     def empty(self, *shape, dtype=None):
         return torch.empty(*shape, dtype=dtype or self.dtype, device=self.torch_device)

@@ -1,0 +1,84 @@
+"""world_size-2 gloo tests (CPU) of the multi-GPU sharding logic: the sharded chunk loop must reproduce the
+single-process sampler bit-for-bit, and the frame sharder / C1 gather must return frames in order."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from star_amd.diffusion import GaussianDiffusion, noise_schedule
+        from star_amd.geometry import make_chunks
+        from star_amd.parallel import ChunkSharder, FrameSharder, gather_frames
+        sig = noise_schedule(schedule="logsnr_cosine_interp", n=1000, zero_terminal_snr=True, scale_min=2.0, scale_max=4.0)
+        gd = GaussianDiffusion(sig)
+        g = torch.Generator().manual_seed(5)
+        A = torch.randn(4, 4, generator=g) * 0.3
+
+        def model(x, t, y=None, hint=None, hint_chunk=None, variant_info=None):
+            h_ = hint_chunk if hint_chunk is not None else hint
+            return torch.einsum("oc,bcfhw->bofhw", A, x) * (1.0 + 0.1 * float(y.mean())) + 0.05 * h_ + 0.001 * float(t[0])
+
+        class Noise:
+            def __init__(self, x, a, b, seed=None):
+                self.g = torch.Generator().manual_seed(99)
+                self.shape = x.shape
+
+            def __call__(self, s, sn):
+                return torch.randn(self.shape, generator=self.g)
+
+        F_ = 72
+        noise = torch.randn(1, 4, F_, 10, 8, generator=g)
+        hint = torch.randn(1, 4, F_, 10, 8, generator=g)
+        y1, y2 = torch.randn(1, 77, 16, generator=g), torch.randn(1, 77, 16, generator=g)
+        res = {}
+        for mx in (16, 32):   # 8 chunks (cfg3 layout) and 3 chunks (ragged over 2 ranks)
+            chunks = make_chunks(F_, 0, mx)
+            kw = dict(noise=noise, model=model, model_kwargs=[{"y": y1}, {"y": y2}, {"hint": hint}], guide_scale=7.5, guide_rescale=0.2,
+                      solver_mode="normal", steps=3, t_max=899, t_min=0, discretization="trailing", chunk_inds=chunks, noise_sampler_cls=Noise)
+            single = gd.sample_sr(**kw)
+            sharded = gd.sample_sr(chunk_executor=ChunkSharder(), **kw)
+            res[f"chunks{mx}"] = bool(torch.equal(single, sharded))
+        z = torch.arange(11 * 2 * 3, dtype=torch.float32).reshape(11, 2, 3)
+        groups = [(i, min(i + 3, 11)) for i in range(0, 11, 3)]
+        out = FrameSharder().map_groups(groups, lambda a, b: z[a:b] * 2)
+        res["frames"] = bool(torch.equal(out, z * 2))
+        clip = torch.full((1, 3, 2, 4, 4), float(rank))
+        allc = gather_frames(clip)
+        res["gather"] = all(float(allc[r].mean()) == r for r in range(world))
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_chunk_and_frame_sharding_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, res in results:
+        assert all(res.values()), (rank, res)

@@ -1,0 +1,46 @@
+"""End-to-end `VideoToVideo_sr.test()` on the GPU against the CPU oracle pipeline (oracle/pipeline_oracle.py) with
+identical weights, inputs and injected noise.  BASELINE.json's parity statement: PSNR of the decoded output vs the
+CPU reference path.  Reduced-width UNet/VAE so that the CPU oracle finishes in about a minute; the padded frame is the
+real 720x1280 (latent 90x160), i.e. BASELINE config[0]'s geometry."""
+import math
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+torch.set_grad_enabled(False)
+
+
+def psnr(a, b, data_range=2.0):
+    mse = float((a.float() - b.float()).pow(2).mean())
+    return 10 * math.log10(data_range ** 2 / max(mse, 1e-30))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,min_psnr", [(torch.float16, 45.0), (torch.bfloat16, 30.0)], ids=["f16", "bf16"])
+def test_pipeline_psnr_vs_cpu_oracle(dtype, min_psnr):
+    import pipeline_oracle as PO
+    from star_amd.topology import SMALL_TEST_CONFIG, random_state_dict
+    from star_amd.vae_topology import VaeConfig, random_vae_state_dict
+    from star_amd.video_to_video_model import VideoToVideo_sr
+    ucfg = SMALL_TEST_CONFIG
+    vcfg = VaeConfig(block_out_channels=(64, 64, 128, 128))
+    sd, vsd = random_state_dict(ucfg, seed=0), random_vae_state_dict(vcfg, seed=0)
+    g = torch.Generator().manual_seed(666)
+    frames = 4
+    video = (torch.randn(frames, 3, 32, 32, generator=g) * 0.5).clamp(-1, 1)
+    y = torch.randn(1, 77, ucfg.context_dim, generator=g)
+    neg = torch.randn(1, 77, ucfg.context_dim, generator=g)
+    kw = dict(total_noise_levels=900, steps=3, solver_mode="normal", guide_scale=7.5, max_chunk_len=32)
+    ref, aux = PO.run_pipeline(sd, vsd, ucfg, vcfg, video, y, neg, (128, 128), torch.Generator().manual_seed(1), **kw)
+    model = VideoToVideo_sr(dict(state_dict=sd, vae_state_dict=vsd, unet_config=ucfg, vae_config=vcfg, dtype=dtype, negative_y=neg,
+                                 rng=torch.Generator().manual_seed(1)))
+    out = model.test({"video_data": video.cuda(), "y": y, "target_res": (128, 128)}, **kw)
+    assert out.shape == ref.shape == (1, 3, frames, 128, 128) and out.dtype == torch.float32 and out.device.type == "cpu"
+    p = psnr(out, ref, data_range=float(ref.max() - ref.min()))
+    print(f"pipeline PSNR vs CPU oracle ({dtype}): {p:.1f} dB; ref range [{float(ref.min()):.2f}, {float(ref.max()):.2f}]")
+    assert torch.isfinite(out).all()
+    assert p >= min_psnr, p
