@@ -4,6 +4,8 @@
 #include "unet.h"
 #include "vae.h"
 #include <cstring>
+#include <cstdio>
+#include <cstdlib>
 
 using namespace star;
 
@@ -164,6 +166,12 @@ int star_profile_begin(star_ctx* h) {
 }
 int star_profile_end(star_ctx* h, star_prof_entry* out) {
   rt::stream_sync(h->c.stream);
+  if (const char* path = getenv("STAR_PROF_DETAIL")) {   // per-launch records: kind, dims, ms
+    if (FILE* f = fopen(path, "a")) {
+      for (auto& r : h->c.prof) fprintf(f, "%d,%d,%d,%d,%d,%.6f,%.6g\n", r.kind, r.d0, r.d1, r.d2, r.d3, rt::event_elapsed_ms(r.e0, r.e1), r.flops);
+      fclose(f);
+    }
+  }
   for (int k = 0; k < PK_COUNT; ++k) out[k] = star_prof_entry{0, 0, 0, 0, 0, 0};
   for (auto& r : h->c.prof) {
     const double ms = rt::event_elapsed_ms(r.e0, r.e1);

@@ -23,7 +23,8 @@ int op_flash_attn(Ctx* ctx, const AttnArgs& a) {
   if (a.Nq <= 0 || a.Nk <= 0 || a.batch * a.heads <= 0) return 0;
   if ((a.ldq | a.ldk | a.ldv | a.ldo) & 7) return ctx->fail("flash_attn: row strides must be multiples of 8 elements");
   ProfScope ps(ctx, a.bsk == 0 && a.batch > 1 ? PK_ATTN_CROSS : PK_ATTN_SELF, 4.0 * a.batch * a.heads * (double)a.Nq * a.Nk * 64.0,
-               2.0 * a.batch * a.heads * 64.0 * (2.0 * a.Nq + 2.0 * (a.bsk == 0 ? a.Nk / (double)a.batch : a.Nk)));
+               2.0 * a.batch * a.heads * 64.0 * (2.0 * a.Nq + 2.0 * (a.bsk == 0 ? a.Nk / (double)a.batch : a.Nk)),
+               a.batch, a.heads, a.Nq, a.Nk);
   if (ctx->dtype == DT_F16) return launch_flash<f16>(ctx, a);
   if (ctx->dtype == DT_BF16) return launch_flash<bf16>(ctx, a);
   return ctx->fail("flash_attn: unsupported dtype");

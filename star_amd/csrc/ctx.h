@@ -96,7 +96,7 @@ struct VaeModel;
 
 // per-kernel-family timing with HIP events on the launch stream (bench.py roofline leg)
 enum ProfKind : int { PK_ATTN_SELF = 0, PK_ATTN_CROSS, PK_TATTN, PK_GEMM, PK_CONV, PK_TCONV, PK_GN, PK_LN, PK_MISC, PK_COUNT };
-struct ProfRec { int kind; double flops; double bytes; void* e0; void* e1; };
+struct ProfRec { int kind; double flops; double bytes; void* e0; void* e1; int d0, d1, d2, d3; };
 
 struct Ctx {
   int device = 0;

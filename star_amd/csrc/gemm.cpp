@@ -4,8 +4,8 @@
 
 namespace star {
 
-template <class T, int BM, int BN, int WM, int WN>
-static int launch_gemm_t(Ctx* ctx, const GemmArgs& a) {
+template <class T, int BM, int BN, int WM, int WN, int MINW, bool F32OUT>
+static int launch_gemm_f(Ctx* ctx, const GemmArgs& a) {
   GemmParams p{};
   p.A = a.A; p.W = a.W; p.C = a.C; p.bias = a.bias; p.res = a.res; p.zero_page = ctx->zero_page;
   p.M = a.M; p.N = a.N; p.K = a.K; p.lda = a.lda; p.ldc = a.ldc; p.ldr = a.ldr;
@@ -16,13 +16,19 @@ static int launch_gemm_t(Ctx* ctx, const GemmArgs& a) {
   const size_t smem = 2 * (size_t)(BM + BN) * 128;
   dim3 grid((unsigned)(p.tiles_m * p.tiles_n)), block(WM * WN * 64);
   switch (a.mode) {
-    case A_PLAIN: STAR_LAUNCH((gemm_kernel<T, BM, BN, WM, WN, A_PLAIN>), grid, block, smem, ctx->stream, p); break;
-    case A_CONV3X3: STAR_LAUNCH((gemm_kernel<T, BM, BN, WM, WN, A_CONV3X3>), grid, block, smem, ctx->stream, p); break;
-    case A_CONV3X3_UP: STAR_LAUNCH((gemm_kernel<T, BM, BN, WM, WN, A_CONV3X3_UP>), grid, block, smem, ctx->stream, p); break;
-    case A_TCONV3: STAR_LAUNCH((gemm_kernel<T, BM, BN, WM, WN, A_TCONV3>), grid, block, smem, ctx->stream, p); break;
+    case A_PLAIN: STAR_LAUNCH((gemm_kernel<T, BM, BN, WM, WN, A_PLAIN, MINW, F32OUT>), grid, block, smem, ctx->stream, p); break;
+    case A_CONV3X3: STAR_LAUNCH((gemm_kernel<T, BM, BN, WM, WN, A_CONV3X3, MINW, F32OUT>), grid, block, smem, ctx->stream, p); break;
+    case A_CONV3X3_UP: STAR_LAUNCH((gemm_kernel<T, BM, BN, WM, WN, A_CONV3X3_UP, MINW, F32OUT>), grid, block, smem, ctx->stream, p); break;
+    case A_TCONV3: STAR_LAUNCH((gemm_kernel<T, BM, BN, WM, WN, A_TCONV3, MINW, F32OUT>), grid, block, smem, ctx->stream, p); break;
     default: return ctx->fail("gemm: bad A mode");
   }
   return 0;
+}
+
+template <class T, int BM, int BN, int WM, int WN, int MINW>
+static int launch_gemm_t(Ctx* ctx, const GemmArgs& a) {
+  if (a.epi & EPI_OUT_F32) return launch_gemm_f<T, BM, BN, WM, WN, MINW, true>(ctx, a);
+  return launch_gemm_f<T, BM, BN, WM, WN, MINW, false>(ctx, a);
 }
 
 template <class T>
@@ -31,15 +37,17 @@ static int launch_gemm(Ctx* ctx, const GemmArgs& a) {
   if (!tile) {
     const bool geglu = (a.epi & EPI_GEGLU) != 0;
     if (a.M <= 4096 && a.N <= 1024) tile = 3;                          // small problems: more, smaller tiles
-    else if (!geglu && a.N % 320 == 0 && a.N % 256 != 0) tile = 2;      // 320 / 640 / 960 / 1920-wide layers
+    else if (!geglu && a.N % 320 == 0) tile = 2;                        // 320 / 640 / 960 / 1280 / 1920-wide layers
     else if (a.N <= 128) tile = 4;
     else tile = 1;
   }
   switch (tile) {
-    case 1: return launch_gemm_t<T, 256, 256, 4, 2>(ctx, a);
-    case 2: return launch_gemm_t<T, 256, 320, 4, 2>(ctx, a);
-    case 3: return launch_gemm_t<T, 128, 128, 2, 2>(ctx, a);
-    case 4: return launch_gemm_t<T, 256, 128, 4, 1>(ctx, a);
+    // 8 waves per workgroup (2 per SIMD, <= 256 VGPRs each; 192 / 236 used, no spills): measured 1.3-3.6x faster than
+    // 4-wave variants of the same tiles on the K = 320 layers (profiles/r01_gemm_tile_sweep.txt)
+    case 1: return launch_gemm_t<T, 256, 256, 4, 2, 2>(ctx, a);
+    case 2: return launch_gemm_t<T, 256, 320, 4, 2, 2>(ctx, a);
+    case 3: return launch_gemm_t<T, 128, 128, 2, 2, 2>(ctx, a);
+    case 4: return launch_gemm_t<T, 256, 128, 4, 1, 1>(ctx, a);
   }
   return ctx->fail("gemm: bad tile id");
 }
@@ -50,11 +58,17 @@ int op_gemm(Ctx* ctx, const GemmArgs& a) {
   if (a.mode != A_PLAIN && a.Cin % 64 != 0) return ctx->fail("gemm: conv Cin must be a multiple of 64");
   if ((a.epi & EPI_GEGLU) && (a.N % 64 != 0)) return ctx->fail("gemm: GEGLU needs N % 64 == 0");
   if ((a.epi & EPI_GEGLU) && (a.epi & EPI_OUT_F32)) return ctx->fail("gemm: GEGLU with fp32 output is not supported");
+  if (a.epi & EPI_OUT_F32) {
+    if (a.N % 4 || a.ldc % 4 || ((a.epi & EPI_RES) && a.ldr % 4)) return ctx->fail("gemm: fp32 output needs N, ldc (and ldr) multiples of 4");
+  } else {
+    if (a.N % 8 || a.ldc % 8 || ((a.epi & EPI_RES) && a.ldr % 8)) return ctx->fail("gemm: N, ldc (and ldr) must be multiples of 8");
+  }
   if (a.M <= 0 || a.N <= 0) return 0;
   const double taps = a.mode == A_PLAIN ? 1.0 : 1.0;
   (void)taps;
   ProfScope ps(ctx, a.mode == A_PLAIN ? PK_GEMM : (a.mode == A_TCONV3 ? PK_TCONV : PK_CONV), 2.0 * a.M * (double)a.N * a.K,
-               ((double)a.M * (a.mode == A_PLAIN ? a.K : a.Cin) + (double)a.M * ((a.epi & EPI_GEGLU) ? a.N / 2 : a.N)) * 2.0);
+               ((double)a.M * (a.mode == A_PLAIN ? a.K : a.Cin) + (double)a.M * ((a.epi & EPI_GEGLU) ? a.N / 2 : a.N)) * 2.0,
+               a.M, a.N, a.K, a.epi);
   if (ctx->dtype == DT_F16) return launch_gemm<f16>(ctx, a);
   if (ctx->dtype == DT_BF16) return launch_gemm<bf16>(ctx, a);
   return ctx->fail("gemm: unsupported dtype");

@@ -43,8 +43,8 @@ struct GemmParams {
 
 STAR_DEV float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
-template <class T, int BM, int BN, int WM, int WN, int AMODE>
-STAR_GLOBAL void STAR_LAUNCH_BOUNDS(WM * WN * 64)
+template <class T, int BM, int BN, int WM, int WN, int AMODE, int MINW, bool F32OUT>
+STAR_GLOBAL void STAR_LAUNCH_BOUNDS(WM * WN * 64, MINW)
 gemm_kernel(const GemmParams p) {
   constexpr int NT = WM * WN * 64;
   constexpr int BK = 64;
@@ -193,10 +193,11 @@ gemm_kernel(const GemmParams p) {
   }
 
   // ------------------------------------------------------------------ epilogue
-  // lane holds, for m = i*32 + (lane&31): n = j*32 + 8*(r>>2) + 4*(lane>>5) + (r&3)
-  if (p.epi & EPI_OUT_F32) {
+  // lane holds, for m = i*32 + (lane&31): n = j*32 + 8*(r>>2) + 4*(lane>>5) + (r&3).  N % 8 == 0 (T out) / N % 4 == 0
+  // (fp32 out) is checked by the launcher, so every 4-/8-column group is either fully inside or fully outside.
+  if constexpr (F32OUT) {
     // exact fp32 results straight from the accumulators (attention logits of the VAE, final latent prediction):
-    // 16-B stores of 4 consecutive n per lane; rows differ per lane (not staged: fp32 tiles do not fit the LDS budget)
+    // one 16-B store of 4 consecutive n per lane (fp32 tiles do not fit the LDS staging budget)
     const float* __restrict__ biasf = p.bias;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -206,108 +207,87 @@ gemm_kernel(const GemmParams p) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int n = n0 + wn * WTN + j * 32 + 8 * g + 4 * fhalf;
-          if (m >= p.M || n >= p.N) continue;
-          float v[4];
+          if (m < p.M && n < p.N) {
+            f32x4 o;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            v[e] = acc[i][j][g * 4 + e];
-            if ((p.epi & EPI_BIAS) && n + e < p.N) v[e] += biasf[n + e];
-            if ((p.epi & EPI_RES) && n + e < p.N) v[e] += to_f32<T>(((const T*)p.res)[(size_t)m * p.ldr + n + e]);
-          }
-          float* cp = (float*)p.C + (size_t)m * p.ldc + n;
-          if (n + 4 <= p.N && ((p.ldc & 3) == 0)) {
-            f32x4 o; o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
-            *reinterpret_cast<f32x4*>(cp) = o;
-          } else {
-            for (int e = 0; e < 4 && n + e < p.N; ++e) cp[e] = v[e];
+            for (int e = 0; e < 4; ++e) o[e] = acc[i][j][g * 4 + e];
+            if (p.epi & EPI_BIAS) { const f32x4 b = *reinterpret_cast<const f32x4*>(biasf + n); o += b; }
+            if (p.epi & EPI_RES) {
+              const vec<T, 4> r = *reinterpret_cast<const vec<T, 4>*>((const T*)p.res + (size_t)m * p.ldr + n);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] += to_f32<T>(r[e]);
+            }
+            *reinterpret_cast<f32x4*>((float*)p.C + (size_t)m * p.ldc + n) = o;
           }
         }
     }
-    return;
-  }
-  const bool geglu = (p.epi & EPI_GEGLU) != 0;
-  constexpr int OUT_TN_MAX = TN;
-  const int out_wtn = geglu ? WTN / 2 : WTN;       // output columns per wave
-  const int out_n0 = geglu ? (n0 + wn * WTN) / 2 : (n0 + wn * WTN);
-  const int N_out = geglu ? p.N / 2 : p.N;
-  const int pitch = WTN * 2 + 8;                    // bytes; (pitch/4) % 4 == 2 -> conflict-free b64 writes
-  block_sync();                                     // all MFMA reads of the stages are done
-  char* my = smem + wave * (32 * (WTN * 2 + 8));
-  const float* __restrict__ bias = p.bias;
+  } else {
+    const bool geglu = (p.epi & EPI_GEGLU) != 0;
+    const int out_wtn = geglu ? WTN / 2 : WTN;       // output columns per wave
+    const int out_n0 = geglu ? (n0 + wn * WTN) / 2 : (n0 + wn * WTN);
+    const int N_out = geglu ? p.N / 2 : p.N;
+    constexpr int pitch = WTN * 2 + 8;                // bytes; (pitch/4) % 4 == 2 -> conflict-free b64 writes
+    block_sync();                                     // all MFMA reads of the stages are done
+    char* my = smem + wave * (32 * pitch);
+    const float* __restrict__ bias = p.bias;
+    const int cpr = out_wtn / 8;                      // 16-B chunks per row
+    const int nchunks = 32 * cpr;
 
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    // ---- registers -> LDS (T, row-major [32][out_wtn])
+    for (int i = 0; i < TM; ++i) {
+      // ---- registers -> LDS (T, row-major [32][out_wtn])
 #pragma unroll
-    for (int j = 0; j < OUT_TN_MAX; ++j) {
-      if (geglu && (j & 1)) continue;
+      for (int j = 0; j < TN; ++j) {
+        if (geglu && (j & 1)) continue;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int nl = j * 32 + 8 * g + 4 * fhalf;   // local n within wave tile (pre-GEGLU)
-        float v[4];
+        for (int g = 0; g < 4; ++g) {
+          const int nl = j * 32 + 8 * g + 4 * fhalf;  // local n within the wave tile (pre-GEGLU)
+          int ng = n0 + wn * WTN + nl;
+          f32x4 v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][g * 4 + e];
-        if (p.epi & EPI_BIAS) {
-          const int ng = n0 + wn * WTN + nl;
+          for (int e = 0; e < 4; ++e) v[e] = acc[i][j][g * 4 + e];
+          if (ng > p.N - 4) ng = p.N - 4;             // columns past N are never stored; keep the bias load in range
+          if (p.epi & EPI_BIAS) v += *reinterpret_cast<const f32x4*>(bias + ng);
+          int ncol = nl;
+          if (geglu) {
+            f32x4 gt;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += bias[(ng + e < p.N) ? ng + e : p.N - 1];
-        }
-        int ncol = nl;
-        if (geglu) {
-          float gt[4];
+            for (int e = 0; e < 4; ++e) gt[e] = acc[i][(j + 1 < TN) ? j + 1 : j][g * 4 + e];
+            int ngg = ng + 32;
+            if (ngg > p.N - 4) ngg = p.N - 4;
+            if (p.epi & EPI_BIAS) gt += *reinterpret_cast<const f32x4*>(bias + ngg);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) gt[e] = acc[i][(j + 1 < TN) ? j + 1 : j][g * 4 + e];
-          if (p.epi & EPI_BIAS) {
-            const int ng = n0 + wn * WTN + nl + 32;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) gt[e] += bias[(ng + e < p.N) ? ng + e : p.N - 1];
+            for (int e = 0; e < 4; ++e) v[e] = v[e] * gelu_erf(gt[e]);
+            ncol = (j >> 1) * 32 + 8 * g + 4 * fhalf;
           }
+          vec<T, 4> o;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = v[e] * gelu_erf(gt[e]);
-          ncol = (j >> 1) * 32 + 8 * g + 4 * fhalf;
-        }
-        vec<T, 4> o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = from_f32<T>(v[e]);
-        *reinterpret_cast<vec<T, 4>*>(my + frow * pitch + ncol * 2) = o;
-      }
-    }
-    block_sync();
-    // ---- LDS -> global, 16-B chunks along rows
-    const int cpr = out_wtn / 8;  // chunks per row
-    const int nchunks = 32 * cpr;
-    for (int q = lane; q < nchunks; q += 64) {
-      const int row = q / cpr, cc = q - row * cpr;
-      const int m = m0 + wm * WTM + i * 32 + row;
-      const int n = out_n0 + cc * 8;
-      if (m >= p.M || n >= N_out) continue;
-      vec<T, 4> lo = *reinterpret_cast<const vec<T, 4>*>(my + row * pitch + cc * 16);
-      vec<T, 4> hi = *reinterpret_cast<const vec<T, 4>*>(my + row * pitch + cc * 16 + 8);
-      float v[8];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { v[e] = to_f32<T>(lo[e]); v[4 + e] = to_f32<T>(hi[e]); }
-      const bool full = (n + 8 <= N_out);
-      if (p.epi & EPI_RES) {
-        const T* rp = (const T*)p.res + (size_t)m * p.ldr + n;
-        if (full && ((p.ldr & 7) == 0)) {
-          vec<T, 8> rv = *reinterpret_cast<const vec<T, 8>*>(rp);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += to_f32<T>(rv[e]);
-        } else {
-          for (int e = 0; e < 8 && n + e < N_out; ++e) v[e] += to_f32<T>(rp[e]);
+          for (int e = 0; e < 4; ++e) o[e] = from_f32<T>(v[e]);
+          *reinterpret_cast<vec<T, 4>*>(my + frow * pitch + ncol * 2) = o;
         }
       }
-      T* cp = (T*)p.C + (size_t)m * p.ldc + n;
-      if (full && ((p.ldc & 7) == 0)) {
-        vec<T, 8> ov;
+      block_sync();
+      // ---- LDS -> global: whole 16-B chunks along rows (+ residual)
+      for (int q = lane; q < nchunks; q += 64) {
+        const int row = q / cpr, cc = q - row * cpr;
+        const int m = m0 + wm * WTM + i * 32 + row;
+        const int n = out_n0 + cc * 8;
+        if (m < p.M && n < N_out) {
+          const vec<T, 4> lo = *reinterpret_cast<const vec<T, 4>*>(my + row * pitch + cc * 16);
+          const vec<T, 4> hi = *reinterpret_cast<const vec<T, 4>*>(my + row * pitch + cc * 16 + 8);
+          vec<T, 8> ov;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) ov[e] = from_f32<T>(v[e]);
-        *reinterpret_cast<vec<T, 8>*>(cp) = ov;
-      } else {
-        for (int e = 0; e < 8 && n + e < N_out; ++e) cp[e] = from_f32<T>(v[e]);
+          for (int e = 0; e < 4; ++e) { ov[e] = lo[e]; ov[4 + e] = hi[e]; }
+          if (p.epi & EPI_RES) {
+            const vec<T, 8> rv = *reinterpret_cast<const vec<T, 8>*>((const T*)p.res + (size_t)m * p.ldr + n);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ov[e] = from_f32<T>(to_f32<T>(ov[e]) + to_f32<T>(rv[e]));
+          }
+          *reinterpret_cast<vec<T, 8>*>((T*)p.C + (size_t)m * p.ldc + n) = ov;
+        }
       }
+      block_sync();
     }
-    block_sync();
   }
 }
 

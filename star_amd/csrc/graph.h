@@ -75,11 +75,20 @@ struct Builder {
     return l;
   }
   // Conv2d 3x3 [N, C, 3, 3] -> [N][tap][C] (K = 9C, tap-major), tap = ky*3 + kx
-  LinW conv3x3(const std::string& p) {
+  LinW conv3x3(const std::string& p, int pad_n_to = 1) {
     LinW l;
     const HostTensor* w = get(p + ".weight");
     if (!w) return l;
-    const int N = (int)w->shape[0], C = (int)w->shape[1];
+    const int N0 = (int)w->shape[0], C = (int)w->shape[1];
+    const int N = (N0 + pad_n_to - 1) / pad_n_to * pad_n_to;   // zero rows up to a multiple (fp32-out GEMMs need N % 4 == 0)
+    if (N != N0) {
+      std::vector<float> r((size_t)N * 9 * C, 0.f), rb(N, 0.f);
+      const HostTensor* bb = get(p + ".bias");
+      if (!bb) return l;
+      for (int n = 0; n < N0; ++n) { rb[n] = bb->data[n]; for (int c = 0; c < C; ++c) for (int t = 0; t < 9; ++t) r[((size_t)n * 9 + t) * C + c] = w->data[((size_t)n * C + c) * 9 + t]; }
+      l.N = N; l.K = 9 * C; l.w = upload_T(r); l.b = upload_f32(rb);
+      return l;
+    }
     std::vector<float> r((size_t)N * 9 * C);
     for (int n = 0; n < N; ++n) for (int c = 0; c < C; ++c) for (int t = 0; t < 9; ++t)
       r[((size_t)n * 9 + t) * C + c] = w->data[((size_t)n * C + c) * 9 + t];

@@ -9,9 +9,9 @@ namespace star {
 // RAII: brackets one kernel launch with HIP events when ctx->profiling is on
 struct ProfScope {
   Ctx* ctx; int idx = -1;
-  ProfScope(Ctx* c, int kind, double flops, double bytes) : ctx(c) {
+  ProfScope(Ctx* c, int kind, double flops, double bytes, int d0 = 0, int d1 = 0, int d2 = 0, int d3 = 0) : ctx(c) {
     if (!c->profiling) return;
-    ProfRec r{kind, flops, bytes, rt::event_record(c->stream), nullptr};
+    ProfRec r{kind, flops, bytes, rt::event_record(c->stream), nullptr, d0, d1, d2, d3};
     c->prof.push_back(r);
     idx = (int)c->prof.size() - 1;
   }

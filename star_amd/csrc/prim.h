@@ -48,8 +48,12 @@ template <>
 STAR_DEV float to_f32<float>(float v) { return v; }
 template <>
 STAR_DEV float to_f32<bf16>(bf16 v) {
+#ifdef STAR_HOSTEMU
   uint16_t b = __builtin_bit_cast(uint16_t, v);
   return __builtin_bit_cast(float, (uint32_t)b << 16);
+#else
+  return (float)v;
+#endif
 }
 template <class T>
 STAR_DEV T from_f32(float v);
@@ -59,6 +63,9 @@ template <>
 STAR_DEV float from_f32<float>(float v) { return v; }
 template <>
 STAR_DEV bf16 from_f32<bf16>(float v) {  // round-to-nearest-even, NaN preserved
+#ifndef STAR_HOSTEMU
+  return (bf16)v;   // gfx950: v_cvt_pk_bf16_f32
+#endif
   uint32_t u = __builtin_bit_cast(uint32_t, v);
   if ((u & 0x7fffffffu) > 0x7f800000u) return __builtin_bit_cast(bf16, (uint16_t)((u >> 16) | 0x40));
   u += 0x7fffu + ((u >> 16) & 1u);

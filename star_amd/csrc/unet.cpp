@@ -318,7 +318,7 @@ static int build_net(UBuilder& b, const UNetCfg& cfg, bool control, Net& net) {
       }
     }
     net.out_norm = b.norm("out.0");
-    net.out_conv = b.conv3x3("out.2");
+    net.out_conv = b.conv3x3("out.2", 4);
   }
   return b.err.empty() ? 0 : 1;
 }

@@ -187,7 +187,7 @@ int vae_build(Ctx* ctx, const VaeCfg& cfg) {
     if (i != nb - 1) M->d_up.push_back(b.conv3x3("decoder.up_blocks." + std::to_string(i) + ".upsamplers.0.conv"));
   }
   M->d_norm_out = b.norm("decoder.conv_norm_out");
-  M->d_conv_out = b.conv3x3("decoder.conv_out");
+  M->d_conv_out = b.conv3x3("decoder.conv_out", 4);
   M->d_time_w = b.raw_f32("decoder.time_conv_out.weight");
   M->d_time_b = b.raw_f32("decoder.time_conv_out.bias");
   if (!b.err.empty()) return ctx->fail("vae_build: " + b.err);

@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--only", default="")
     ap.add_argument("--out", default="")
+    ap.add_argument("--tiles", default="")
     args = ap.parse_args()
     dt = {"bf16": torch.bfloat16, "f16": torch.float16}[args.dtype]
     only = set(args.only.split(",")) if args.only else None
@@ -88,8 +89,11 @@ def main():
             Wt = torch.randn(N, K, device=dev, dtype=dt) * 0.05
             b = torch.randn(N, device=dev)
             out = torch.empty(M, N // 2 if geglu else N, device=dev, dtype=dt)
-            s = timeit(lambda: ctx.gemm(A, Wt, bias=b, out=out, geglu=geglu))
-            rec(f"gemm {tag} M={M} N={N} K={K}", s, flops=2.0 * M * N * K, bytes_=(A.numel() + out.numel()) * 2)
+            for tile in ([0] if not args.tiles else [int(t) for t in args.tiles.split(",")]):
+                if geglu and tile in (2, 6):
+                    continue
+                s = timeit(lambda: ctx.gemm(A, Wt, bias=b, out=out, geglu=geglu, force_tile=tile))
+                rec(f"gemm {tag} M={M} N={N} K={K} tile={tile}", s, flops=2.0 * M * N * K, bytes_=(A.numel() + out.numel()) * 2)
             del A, Wt, out
     if want("conv"):
         for (NB, Cin, Hh, Ww, Cout, tag) in [(32, 320, 122, 216, 320, "L0 320->320"), (32, 640, 62, 108, 640, "L1 640->640"),
