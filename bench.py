@@ -164,7 +164,9 @@ def run_cpu_baseline(sd, ucfg, args):
     import unet_oracle as O
     from make_golden import unet_inputs
     from torch.utils.flop_counter import FlopCounterMode
-    cores = os.cpu_count() or 1
+    # torch's CPU kernels stop scaling (and collapse) far below this box's hardware thread count on these small
+    # tensors: 256 threads ran the same sample at 5 GFLOP/s vs ~400 GFLOP/s on 8; use a bounded, stated thread count
+    cores = min(32, os.cpu_count() or 1)
     torch.set_num_threads(cores)
     f, h, w = 8, 26, 24
     x, t, y, hint = unet_inputs(ucfg, f, h, w, 7)
@@ -178,6 +180,7 @@ def run_cpu_baseline(sd, ucfg, args):
     evals = 14 if args.solver_mode == "fast" else args.denoise_steps
     total = (2 * evals * UNET_FWD_TFLOP_CFG2 + args.frames * VAE_TFLOP_PER_FRAME) * 1e12
     return {"value": args.frames / (total / cpu_flops), "unit": "frames/s", "cores": cores, "kind": "port",
+            "host_threads_available": os.cpu_count(),
             "sample": f"one UNet+ControlNet forward of the fp32 CPU oracle at f={f}, latent {h}x{w} ({flops / 1e12:.2f} TFLOP in {secs:.1f} s = "
                       f"{cpu_flops / 1e9:.0f} GFLOP/s); frames/s EXTRAPOLATED by FLOP ratio to the {total / 1e15:.1f} PFLOP workload",
             "measured_gflops": cpu_flops / 1e9, "sample_seconds": secs}

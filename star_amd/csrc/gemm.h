@@ -41,7 +41,16 @@ struct GemmParams {
   int tiles_m, tiles_n;
 };
 
-STAR_DEV float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// exact (erf) GELU, F.gelu default (unet_v2v.py:504).  erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below
+// the 16-bit output rounding): one exp2, one rcp and a 5-term Horner instead of libm's branchy erff in the GEGLU epilogue.
+STAR_DEV float gelu_erf(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = fast_rcp(1.0f + 0.3275911f * z);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float erf_abs = 1.0f - poly * fast_exp2(-1.4426950408889634f * z * z);
+  const float erf_x = x < 0.f ? -erf_abs : erf_abs;
+  return 0.5f * x * (1.0f + erf_x);
+}
 
 template <class T, int BM, int BN, int WM, int WN, int AMODE, int MINW, bool F32OUT>
 STAR_GLOBAL void STAR_LAUNCH_BOUNDS(WM * WN * 64, MINW)
