@@ -65,6 +65,7 @@ typedef struct star_attn_desc {
   int64_t bsq, bsk, bsv, bso;        /* batch (frame) strides in elements; 0 = shared by all batches */
   int32_t Nq, Nk, heads, batch;
   float scale;
+  int32_t variant;                   /* 0 = baseline kernel, 1 = v2 (default) */
 } star_attn_desc;
 int star_attn_fwd(star_ctx* ctx, const star_attn_desc* d);
 

@@ -15,7 +15,9 @@ static int launch_flash(Ctx* ctx, const AttnArgs& a) {
   p.nqb = (a.Nq + 255) / 256;
   const int BH = a.batch * a.heads;
   const long long nblk = 8LL * p.nqb * ((BH + 7) / 8);
-  STAR_LAUNCH((flash_attn_kernel<T>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);
+  p.variant = a.variant;
+  if (a.variant == 0) STAR_LAUNCH((flash_attn_kernel<T>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);
+  else STAR_LAUNCH((flash_attn_v2_kernel<T>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);
   return 0;
 }
 

@@ -14,10 +14,12 @@
 // LDS round trip for P.  V^T fragments come from ds_read_b64_tr_b16.
 #pragma once
 #include "prim.h"
+#include <type_traits>
 
 namespace star {
 
 struct AttnParams {
+  int variant;                       // 0 = baseline kernel, 1 = v2 (staggered streams + deferred rescale)
   const void* Q; const void* K; const void* V; void* O;
   int ldq, ldk, ldv, ldo;            // row strides (elements)
   long long bsq, bsk, bsv, bso;      // batch strides (elements); bsk = bsv = 0 for a shared context
@@ -216,6 +218,210 @@ flash_attn_kernel(const AttnParams p) {
         // lower lane: d = 32db + 16a + 0..7 ; upper lane: d = 32db + 16a + 8..15
         u32x4 out;
         out[0] = s0[0]; out[1] = s1[0]; out[2] = s0[1]; out[3] = s1[1];
+        if (q < p.Nq) *reinterpret_cast<u32x4*>(Og + (size_t)q * p.ldo + 32 * db + 16 * a + 8 * h2) = out;
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// flash_attn_v2_kernel: same contract and tiling as flash_attn_kernel, restructured after PMC analysis of the baseline
+// (profiles/r01_attn_pmc_v0.txt: per wave 37 % VALU-active, 46 % MFMA-issue/dependency stalls, MFMA pipe 38 % busy --
+// QK^T -> softmax -> PV ran as one serial dependency chain per wave, and the key-tail mask cost 64 v_cndmask per tile):
+//   * per tile, ONE early wave-uniform decision (does any row's max grow by more than 2^THR?) -- the rare rescale
+//     branch is taken before any P is exponentiated (textbook order), everything after it is straight-line code;
+//   * in that straight-line block the PV MFMAs of query block 0 sit beside the exp/convert VALU work of query block 1
+//     (independent streams the scheduler can interleave), and PV of block 1 runs into the next tile's QK^T;
+//   * the key-tail mask exists only in the peeled last tile; row max via 3-input max chains; the lane^32 exchange is a
+//     v_permlane32_swap, not an LDS bpermute.
+template <class T>
+STAR_GLOBAL void STAR_LAUNCH_BOUNDS(256, 2)
+flash_attn_v2_kernel(const AttnParams p) {
+  constexpr int QW = 64, QB = 256, KT = 64, TILE = KT * 128;
+  constexpr float RESCALE_THR = 8.0f;   // log2 units: P <= 2^8 before a rescale is forced
+  char* smem = dyn_smem();
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h2 = lane >> 5, lq = lane & 31;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int bh = xcd + 8 * (slot / p.nqb);
+  const int qb = slot % p.nqb;
+  if (bh >= p.batch * p.heads) return;
+  const int b = bh / p.heads, hd = bh % p.heads;
+  const T* __restrict__ Qg = (const T*)p.Q + (size_t)b * p.bsq + hd * 64;
+  const T* __restrict__ Kg = (const T*)p.K + (size_t)b * p.bsk + hd * 64;
+  const T* __restrict__ Vg = (const T*)p.V + (size_t)b * p.bsv + hd * 64;
+  T* __restrict__ Og = (T*)p.O + (size_t)b * p.bso + hd * 64;
+
+  vec<T, 8> qf[2][4];
+  const int q_base = qb * QB + wave * QW;
+#pragma unroll
+  for (int qi = 0; qi < 2; ++qi) {
+    int q = q_base + qi * 32 + lq;
+    if (q > p.Nq - 1) q = p.Nq - 1;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      qf[qi][ks] = *reinterpret_cast<const vec<T, 8>*>(Qg + (size_t)q * p.ldq + ks * 16 + h2 * 8);
+  }
+  const int pos = tid & 7;
+  auto stage = [&](int t, int buf) {
+    char* kbuf = smem + buf * 2 * TILE;
+    char* vbuf = kbuf + TILE;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r = (j * 256 + tid) >> 3;
+      const int c = pos ^ ((r >> 1) & 7);
+      int key = t * KT + r;
+      if (key > p.Nk - 1) key = p.Nk - 1;
+      glds16(Kg + (size_t)key * p.ldk + c * 8, kbuf + (size_t)(j * 256 + wave * 64) * 16);
+      glds16(Vg + (size_t)key * p.ldv + c * 8, vbuf + (size_t)(j * 256 + wave * 64) * 16);
+    }
+  };
+
+  f32x16 oacc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[a][c2][r] = 0.f;
+  float m_run[2] = {-1e30f, -1e30f};
+  float l_run[2] = {0.f, 0.f};
+  const int nt = (p.Nk + KT - 1) / KT;
+  const float c = p.scale_log2e;
+
+  auto tile = [&](int t, auto mask_tag) {
+    constexpr bool MASK = decltype(mask_tag)::value;
+    const char* kbuf = smem + (t & 1) * 2 * TILE;
+    const char* vbuf = kbuf + TILE;
+    // ---- S^T = K Q^T for both query blocks (16 MFMAs, 4 independent accumulators)
+    f32x16 s[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[a][kb][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        const vec<T, 8> kf = *reinterpret_cast<const vec<T, 8>*>(kbuf + swz_off(kb * 32 + lq, ks * 2 + h2));
+#pragma unroll
+        for (int qi = 0; qi < 2; ++qi) s[qi][kb] = mfma32<T>(kf, qf[qi][ks], s[qi][kb]);
+      }
+    if constexpr (MASK) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = t * KT + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
+          if (key >= p.Nk) { s[0][kb][r] = -1e30f; s[1][kb][r] = -1e30f; }
+        }
+    }
+    // ---- row maxima of both blocks, one wave-uniform rescale decision
+    float m_tile[2];
+#pragma unroll
+    for (int qi = 0; qi < 2; ++qi) {
+      float mx[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int kb = g >> 1, o = (g & 1) * 8;
+        const float a0 = fmaxf(fmaxf(s[qi][kb][o], s[qi][kb][o + 1]), s[qi][kb][o + 2]);
+        const float a1 = fmaxf(fmaxf(s[qi][kb][o + 3], s[qi][kb][o + 4]), s[qi][kb][o + 5]);
+        mx[g] = fmaxf(fmaxf(a0, a1), fmaxf(s[qi][kb][o + 6], s[qi][kb][o + 7]));
+      }
+      m_tile[qi] = pair_max(fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3]))) * c;
+    }
+    if (wave_any(m_tile[0] > m_run[0] + RESCALE_THR || m_tile[1] > m_run[1] + RESCALE_THR)) {
+#pragma unroll
+      for (int qi = 0; qi < 2; ++qi) {   // everything still at the old max is rescaled exactly once, before any new P exists
+        const float m_new = fmaxf(m_run[qi], m_tile[qi]);
+        const float alpha = fast_exp2(m_run[qi] - m_new);
+        m_run[qi] = m_new;
+        l_run[qi] *= alpha;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oacc[qi][db][r] *= alpha;
+      }
+    }
+    // ---- straight-line: P0 ; PV0 beside P1 ; PV1
+    vec<T, 8> pf[2][4];
+    auto expo = [&](int qi) {
+      const float m = m_run[qi];
+      float ls0 = 0.f, ls1 = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          vec<T, 8> pk;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float pv = fast_exp2(s[qi][kb][8 * u + e] * c - m);
+            if (e & 1) ls1 += pv; else ls0 += pv;
+            pk[e] = from_f32<T>(pv);
+          }
+          pf[qi][kb * 2 + u] = pk;
+        }
+      l_run[qi] += ls0 + ls1;
+    };
+    expo(0);
+    expo(1);
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        const vec<T, 8> vf = load_vt_frag<T>(vbuf, tt * 16, db, lane);
+        oacc[0][db] = mfma32<T>(vf, pf[0][tt], oacc[0][db]);
+        oacc[1][db] = mfma32<T>(vf, pf[1][tt], oacc[1][db]);
+      }
+#ifndef STAR_HOSTEMU
+    // interleave: the first 8 PV MFMAs (they only need P0) beside the VALU of expo(1)
+    for (int i = 0; i < 8; ++i) {
+      STAR_SCHED_GROUP(0x008, 1, 0);   // 1 MFMA
+      STAR_SCHED_GROUP(0x100, 2, 0);   // 2 DS reads
+      STAR_SCHED_GROUP(0x002, 12, 0);  // 12 VALU
+    }
+#endif
+  };
+
+  stage(0, 0);
+  const bool has_tail = (p.Nk & (KT - 1)) != 0;
+  const int nfull = has_tail ? nt - 1 : nt;
+  for (int t = 0; t < nfull; ++t) {
+    glds_wait();
+    block_sync();
+    if (t + 1 < nt) stage(t + 1, (t + 1) & 1);
+    tile(t, std::false_type{});
+  }
+  if (has_tail) {
+    glds_wait();
+    block_sync();
+    tile(nt - 1, std::true_type{});
+  }
+
+#pragma unroll
+  for (int qi = 0; qi < 2; ++qi) {
+    const float l = pair_sum(l_run[qi]);
+    const float inv = 1.0f / l;
+    const int q = q_base + qi * 32 + lq;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        uint32_t w0[2], w1[2];
+#pragma unroll
+        for (int gg = 0; gg < 2; ++gg) {
+          vec<T, 4> o4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o4[e] = from_f32<T>(oacc[qi][db][(2 * a + gg) * 4 + e] * inv);
+          u32x2 pk = __builtin_bit_cast(u32x2, o4);
+          if (gg == 0) { w0[0] = pk[0]; w0[1] = pk[1]; } else { w1[0] = pk[0]; w1[1] = pk[1]; }
+        }
+        const u32x2 x0 = permlane32_swap(w0[0], w1[0]);
+        const u32x2 x1 = permlane32_swap(w0[1], w1[1]);
+        u32x4 out;
+        out[0] = x0[0]; out[1] = x1[0]; out[2] = x0[1]; out[3] = x1[1];
         if (q < p.Nq) *reinterpret_cast<u32x4*>(Og + (size_t)q * p.ldo + 32 * db + 16 * a + 8 * h2) = out;
       }
   }

@@ -42,6 +42,7 @@ struct AttnArgs {
   long long bsq = 0, bsk = 0, bsv = 0, bso = 0;
   int Nq = 0, Nk = 0, heads = 0, batch = 0;
   float scale = 0.125f;
+  int variant = 1;
 };
 int op_flash_attn(Ctx* ctx, const AttnArgs& a);
 

@@ -244,6 +244,55 @@ STAR_DEV u32x2 permlane32_swap(uint32_t a, uint32_t b) {
   return o;
 #endif
 }
+// lane l <-> lane l^32 exchange through v_permlane32_swap (one VALU op, no LDS): returns the partner's value
+STAR_DEV float xor32(float v) {
+#ifdef STAR_HOSTEMU
+  return shfl_xor(v, 32);
+#else
+  const uint32_t u = __builtin_bit_cast(uint32_t, v);
+  auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);   // r0 = {own | lower's}, r1 = {upper's | own}
+  const uint32_t o = (threadIdx.x & 32) ? r[0] : r[1];
+  return __builtin_bit_cast(float, o);
+#endif
+}
+// max / sum of a value with its lane^32 partner (both halves get the same result)
+STAR_DEV float pair_max(float v) {
+#ifdef STAR_HOSTEMU
+  return fmaxf(v, shfl_xor(v, 32));
+#else
+  const uint32_t u = __builtin_bit_cast(uint32_t, v);
+  auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return fmaxf(__builtin_bit_cast(float, (uint32_t)r[0]), __builtin_bit_cast(float, (uint32_t)r[1]));
+#endif
+}
+STAR_DEV float pair_sum(float v) {
+#ifdef STAR_HOSTEMU
+  return v + shfl_xor(v, 32);
+#else
+  const uint32_t u = __builtin_bit_cast(uint32_t, v);
+  auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __builtin_bit_cast(float, (uint32_t)r[0]) + __builtin_bit_cast(float, (uint32_t)r[1]);
+#endif
+}
+// wave-uniform "any lane has pred"
+STAR_DEV bool wave_any(bool pred) {
+#ifdef STAR_HOSTEMU
+  int v = pred ? 1 : 0;
+  auto st = ::star_emu::wave_exchange(&v, 4);
+  bool any = false;
+  for (int i = 0; i < 64; ++i) { int x; memcpy(&x, st[i], 4); if (x == 1) any = true; }
+  return any;
+#else
+  return __any(pred ? 1 : 0) != 0;
+#endif
+}
+// compile-time scheduling hint (LLVM sched_group_barrier): emit `n` instructions of class `mask` next
+#ifdef STAR_HOSTEMU
+#define STAR_SCHED_GROUP(mask, n, id)
+#else
+#define STAR_SCHED_GROUP(mask, n, id) __builtin_amdgcn_sched_group_barrier((mask), (n), (id))
+#endif
+
 STAR_DEV float wave_sum(float v) {
   for (int m = 32; m >= 1; m >>= 1) v += shfl_xor(v, m);
   return v;

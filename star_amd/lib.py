@@ -33,7 +33,7 @@ class AttnDesc(ctypes.Structure):
         ("ldq", ctypes.c_int32), ("ldk", ctypes.c_int32), ("ldv", ctypes.c_int32), ("ldo", ctypes.c_int32),
         ("bsq", ctypes.c_int64), ("bsk", ctypes.c_int64), ("bsv", ctypes.c_int64), ("bso", ctypes.c_int64),
         ("Nq", ctypes.c_int32), ("Nk", ctypes.c_int32), ("heads", ctypes.c_int32), ("batch", ctypes.c_int32),
-        ("scale", ctypes.c_float),
+        ("scale", ctypes.c_float), ("variant", ctypes.c_int32),
     ]
 
 
@@ -231,7 +231,7 @@ class Context:
         self._check(self.lib.gemm(self.h, ctypes.byref(d)), "gemm")
         return out
 
-    def attention(self, q, k, v, heads, out=None, scale=None):
+    def attention(self, q, k, v, heads, out=None, scale=None, variant=1):
         """softmax(q k^T * scale) v per (batch, head).  q: [B, Nq, heads*64]; k, v: [B or 1, Nk, heads*64]
         (a leading dim of 1 is shared by all batches).  Views with a row stride are fine (fused QKV buffers)."""
         for t in (q, k, v):
@@ -249,6 +249,7 @@ class Context:
         d.bsv = v.stride(0) if v.shape[0] > 1 else 0
         d.Nq, d.Nk, d.heads, d.batch = Nq, Nk, heads, B
         d.scale = float(scale if scale is not None else 64 ** -0.5)
+        d.variant = variant
         self._check(self.lib.attn_fwd(self.h, ctypes.byref(d)), "attn_fwd")
         return out
 

@@ -1,0 +1,34 @@
+"""A/B of the flash-attention kernel variants at the cfg2 shapes (interleaved rounds, same process)."""
+import os, sys, json
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from star_amd import lib as L
+variants = [int(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["0", "1"])]
+dt = {"f16": torch.float16, "bf16": torch.bfloat16}[sys.argv[1] if len(sys.argv) > 1 else "f16"]
+ctx = L.Context(0, dt)
+dev = ctx.torch_device
+def t_ms(fn, iters=3):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+for (B, heads, N, tag) in [(8, 5, 26352, "L0"), (16, 10, 6696, "L1"), (32, 20, 1728, "L2")]:
+    C = heads * 64
+    qkv = torch.randn(B, N, 3 * C, device=dev, dtype=dt)
+    out = torch.empty(B, N, C, device=dev, dtype=dt)
+    flops = 4.0 * B * heads * N * N * 64
+    res = {v: [] for v in variants}
+    for v in variants:
+        ctx.attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], heads, out=out, variant=v)
+    for rnd in range(3):
+        for v in variants:
+            res[v].append(t_ms(lambda: ctx.attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], heads, out=out, variant=v)))
+    print(tag, {v: "%.3f ms %.0f TF/s" % (min(r), flops / min(r) / 1e9) for v, r in res.items()}, flush=True)
+    if len(variants) > 1:
+        o = {}
+        for v in variants:
+            ctx.attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], heads, out=out, variant=v)
+            o[v] = out.float().clone()
+        print("   max |v0 - v%d| = %.2e" % (variants[1], float((o[variants[0]] - o[variants[1]]).abs().max())))
+    del qkv, out
