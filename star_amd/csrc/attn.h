@@ -427,6 +427,235 @@ flash_attn_v2_kernel(const AttnParams p) {
   }
 }
 
+// flash_attn_v3_kernel: v2 plus two VALU-saving moves for the VALU-bound d = 64 regime (PMC: matrix pipe 38 % busy,
+// VALU ~73 %): (1) the softmax scale is folded into Q and the running max into the MFMA through one augmented k-step
+// (K_aug[kv][0] = 1, Q_aug[q][0] = -m_q), so the accumulators already hold (score - max) and P = exp2(acc): 4 extra
+// MFMAs per tile replace 64 v_fma; m_q is kept exactly representable in T, a common row factor cancels in O = PV / l;
+// (2) row sums are taken from the packed (rounded) probabilities with v_dot2c (32 ops instead of 64 adds).
+template <class T, int NQ>   // NQ = 32-row query blocks per wave: 2 -> 2 waves/SIMD (256 VGPRs), 1 -> 4 waves/SIMD (128 VGPRs)
+STAR_GLOBAL void STAR_LAUNCH_BOUNDS(256, (NQ == 2 ? 2 : 4))
+flash_attn_v3_kernel(const AttnParams p) {
+  constexpr int QW = 32 * NQ, QB = 4 * QW, KT = 64, TILE = KT * 128;
+  constexpr float RESCALE_THR = 8.0f;   // log2 units: P <= 2^8 before a rescale is forced
+  char* smem = dyn_smem();
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h2 = lane >> 5, lq = lane & 31;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int bh = xcd + 8 * (slot / p.nqb);
+  const int qb = slot % p.nqb;
+  if (bh >= p.batch * p.heads) return;
+  const int b = bh / p.heads, hd = bh % p.heads;
+  const T* __restrict__ Qg = (const T*)p.Q + (size_t)b * p.bsq + hd * 64;
+  const T* __restrict__ Kg = (const T*)p.K + (size_t)b * p.bsk + hd * 64;
+  const T* __restrict__ Vg = (const T*)p.V + (size_t)b * p.bsv + hd * 64;
+  T* __restrict__ Og = (T*)p.O + (size_t)b * p.bso + hd * 64;
+
+  vec<T, 8> qf[NQ][4];
+  const int q_base = qb * QB + wave * QW;
+#pragma unroll
+  for (int qi = 0; qi < NQ; ++qi) {
+    int q = q_base + qi * 32 + lq;
+    if (q > p.Nq - 1) q = p.Nq - 1;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const vec<T, 8> raw = *reinterpret_cast<const vec<T, 8>*>(Qg + (size_t)q * p.ldq + ks * 16 + h2 * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qf[qi][ks][e] = from_f32<T>(to_f32<T>(raw[e]) * p.scale_log2e);   // softmax scale * log2(e) folded into Q
+    }
+  }
+  // augmented k-step: K_aug[kv][0] = 1, Q_aug[q][0] = -m_run(q) -> the QK^T accumulators come out as (scaled score - running max)
+  vec<T, 8> kaug, qaug[NQ];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    kaug[e] = from_f32<T>(0.f);
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) qaug[qi][e] = from_f32<T>(0.f);
+  }
+  if (h2 == 0) kaug[0] = from_f32<T>(1.0f);
+  const int pos = tid & 7;
+  auto stage = [&](int t, int buf) {
+    char* kbuf = smem + buf * 2 * TILE;
+    char* vbuf = kbuf + TILE;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r = (j * 256 + tid) >> 3;
+      const int c = pos ^ ((r >> 1) & 7);
+      int key = t * KT + r;
+      if (key > p.Nk - 1) key = p.Nk - 1;
+      glds16(Kg + (size_t)key * p.ldk + c * 8, kbuf + (size_t)(j * 256 + wave * 64) * 16);
+      glds16(Vg + (size_t)key * p.ldv + c * 8, vbuf + (size_t)(j * 256 + wave * 64) * 16);
+    }
+  };
+
+  f32x16 oacc[NQ][2];
+#pragma unroll
+  for (int a = 0; a < NQ; ++a)
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[a][c2][r] = 0.f;
+  float m_run[NQ];
+  float l_run[NQ];
+#pragma unroll
+  for (int qi = 0; qi < NQ; ++qi) { m_run[qi] = 0.f; l_run[qi] = 0.f; }
+  //          // always exactly representable in T (it is fed to the MFMA through Q_aug)
+  const int nt = (p.Nk + KT - 1) / KT;
+
+  auto tile = [&](int t, auto mask_tag) {
+    constexpr bool MASK = decltype(mask_tag)::value;
+    const char* kbuf = smem + (t & 1) * 2 * TILE;
+    const char* vbuf = kbuf + TILE;
+    // ---- S^T = K Q^T for both query blocks (16 MFMAs, 4 independent accumulators)
+    f32x16 s[NQ][2];
+#pragma unroll
+    for (int a = 0; a < NQ; ++a)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[a][kb][r] = 0.f;
+        s[a][kb] = mfma32<T>(kaug, qaug[a], s[a][kb]);      // -m_run broadcast over the 32 keys
+      }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        const vec<T, 8> kf = *reinterpret_cast<const vec<T, 8>*>(kbuf + swz_off(kb * 32 + lq, ks * 2 + h2));
+#pragma unroll
+        for (int qi = 0; qi < NQ; ++qi) s[qi][kb] = mfma32<T>(kf, qf[qi][ks], s[qi][kb]);
+      }
+    if constexpr (MASK) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = t * KT + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
+          if (key >= p.Nk) {
+#pragma unroll
+            for (int qi = 0; qi < NQ; ++qi) s[qi][kb][r] = -1e30f;
+          }
+        }
+    }
+    // ---- row maxima (already relative to the running max), one wave-uniform rescale decision
+    float m_tile[NQ];
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) {
+      float mx[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int kb = g >> 1, o = (g & 1) * 8;
+        const float a0 = fmaxf(fmaxf(s[qi][kb][o], s[qi][kb][o + 1]), s[qi][kb][o + 2]);
+        const float a1 = fmaxf(fmaxf(s[qi][kb][o + 3], s[qi][kb][o + 4]), s[qi][kb][o + 5]);
+        mx[g] = fmaxf(fmaxf(a0, a1), fmaxf(s[qi][kb][o + 6], s[qi][kb][o + 7]));
+      }
+      m_tile[qi] = pair_max(fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3])));
+    }
+    bool grow = m_tile[0] > RESCALE_THR;
+    if constexpr (NQ == 2) grow = grow || m_tile[NQ - 1] > RESCALE_THR;
+    if (t == 0 || wave_any(grow)) {
+#pragma unroll
+      for (int qi = 0; qi < NQ; ++qi) {   // rare: move the running max, rescale O / l once, re-base this tile's scores
+        const float inc = (t == 0) ? m_tile[qi] : fmaxf(m_tile[qi], 0.f);
+        const float m_new = to_f32<T>(from_f32<T>(m_run[qi] + inc));
+        const float delta = m_new - m_run[qi];
+        const float alpha = fast_exp2(-delta);
+        m_run[qi] = m_new;
+        l_run[qi] *= alpha;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oacc[qi][db][r] *= alpha;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s[qi][kb][r] -= delta;
+        if (h2 == 0) qaug[qi][0] = from_f32<T>(-m_new);
+      }
+    }
+    // ---- straight-line: P0 ; PV0 beside P1 ; PV1
+    vec<T, 8> pf[NQ][4];
+    auto expo = [&](int qi) {
+      float ls0 = 0.f, ls1 = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          vec<T, 8> pk;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) pk[e] = from_f32<T>(fast_exp2(s[qi][kb][8 * u + e]));
+#pragma unroll
+          for (int e = 0; e < 8; e += 4) {   // row sum of the ROUNDED probabilities (what PV multiplies), 2 per v_dot2c
+            vec<T, 2> a, b2;
+            a[0] = pk[e]; a[1] = pk[e + 1]; b2[0] = pk[e + 2]; b2[1] = pk[e + 3];
+            ls0 = dot2_ones<T>(a, ls0);
+            ls1 = dot2_ones<T>(b2, ls1);
+          }
+          pf[qi][kb * 2 + u] = pk;
+        }
+      l_run[qi] += ls0 + ls1;
+    };
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) expo(qi);
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        const vec<T, 8> vf = load_vt_frag<T>(vbuf, tt * 16, db, lane);
+#pragma unroll
+        for (int qi = 0; qi < NQ; ++qi) oacc[qi][db] = mfma32<T>(vf, pf[qi][tt], oacc[qi][db]);
+      }
+#ifndef STAR_HOSTEMU
+    // interleave: the first 8 PV MFMAs (they only need P0) beside the VALU of expo(1)
+    if constexpr (NQ == 2) for (int i = 0; i < 8; ++i) {
+      STAR_SCHED_GROUP(0x008, 1, 0);   // 1 MFMA
+      STAR_SCHED_GROUP(0x100, 2, 0);   // 2 DS reads
+      STAR_SCHED_GROUP(0x002, 12, 0);  // 12 VALU
+    }
+#endif
+  };
+
+  stage(0, 0);
+  const bool has_tail = (p.Nk & (KT - 1)) != 0;
+  const int nfull = has_tail ? nt - 1 : nt;
+  for (int t = 0; t < nfull; ++t) {
+    glds_wait();
+    block_sync();
+    if (t + 1 < nt) stage(t + 1, (t + 1) & 1);
+    tile(t, std::false_type{});
+  }
+  if (has_tail) {
+    glds_wait();
+    block_sync();
+    tile(nt - 1, std::true_type{});
+  }
+
+#pragma unroll
+  for (int qi = 0; qi < NQ; ++qi) {
+    const float l = pair_sum(l_run[qi]);
+    const float inv = 1.0f / l;
+    const int q = q_base + qi * 32 + lq;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        uint32_t w0[2], w1[2];
+#pragma unroll
+        for (int gg = 0; gg < 2; ++gg) {
+          vec<T, 4> o4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o4[e] = from_f32<T>(oacc[qi][db][(2 * a + gg) * 4 + e] * inv);
+          u32x2 pk = __builtin_bit_cast(u32x2, o4);
+          if (gg == 0) { w0[0] = pk[0]; w0[1] = pk[1]; } else { w1[0] = pk[0]; w1[1] = pk[1]; }
+        }
+        const u32x2 x0 = permlane32_swap(w0[0], w1[0]);
+        const u32x2 x1 = permlane32_swap(w0[1], w1[1]);
+        u32x4 out;
+        out[0] = x0[0]; out[1] = x1[0]; out[2] = x0[1]; out[3] = x1[1];
+        if (q < p.Nq) *reinterpret_cast<u32x4*>(Og + (size_t)q * p.ldo + 32 * db + 16 * a + 8 * h2) = out;
+      }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 struct TAttnParams {
   const void* Q; const void* K; const void* V; void* O;

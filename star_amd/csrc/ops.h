@@ -42,7 +42,7 @@ struct AttnArgs {
   long long bsq = 0, bsk = 0, bsv = 0, bso = 0;
   int Nq = 0, Nk = 0, heads = 0, batch = 0;
   float scale = 0.125f;
-  int variant = 1;
+  int variant = 2;   // 0 baseline, 1 v2, 2 v3 (default: fastest in the A/B, profiles/r01_attn_ab.txt), 3 v3 with 4 waves/SIMD
 };
 int op_flash_attn(Ctx* ctx, const AttnArgs& a);
 

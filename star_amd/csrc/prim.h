@@ -274,6 +274,21 @@ STAR_DEV float pair_sum(float v) {
   return __builtin_bit_cast(float, (uint32_t)r[0]) + __builtin_bit_cast(float, (uint32_t)r[1]);
 #endif
 }
+// acc + a[0] + a[1] in fp32 (v_dot2c_f32_f16 / v_dot2c_f32_bf16 against packed ones): row sums of packed probabilities
+template <class T>
+STAR_DEV float dot2_ones(vec<T, 2> a, float acc) {
+#ifdef STAR_HOSTEMU
+  return acc + to_f32<T>(a[0]) + to_f32<T>(a[1]);
+#else
+  if constexpr (__is_same(T, bf16)) {
+    vec<bf16, 2> one; one[0] = (bf16)1.0f; one[1] = (bf16)1.0f;
+    return __builtin_amdgcn_fdot2_f32_bf16(a, one, acc, false);
+  } else {
+    vec<f16, 2> one; one[0] = (f16)1.0f; one[1] = (f16)1.0f;
+    return __builtin_amdgcn_fdot2(a, one, acc, false);
+  }
+#endif
+}
 // wave-uniform "any lane has pred"
 STAR_DEV bool wave_any(bool pred) {
 #ifdef STAR_HOSTEMU

@@ -166,6 +166,22 @@ def test_flash_attention_cross_77(ctx, dtype):
     assert_close(out, ref_attention(q, kv[..., :128], kv[..., 128:], heads), dtype, what="flash cross")
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+def test_flash_attention_variants_agree(ctx, dtype, variant):
+    """all kernel variants (baseline / v2 / v3 with the augmented-k running max) against the fp32 reference, incl. a
+    ragged key tail, strongly negative logits in tile 0 and a late spike that forces the rescale branch."""
+    g = torch.Generator().manual_seed(21)
+    B, heads, Nq, Nk = 2, 2, 200, 333
+    q = torch.randn(B, Nq, 128, generator=g)
+    k = torch.randn(B, Nk, 128, generator=g)
+    v = torch.randn(B, Nk, 128, generator=g)
+    k[:, :64] = -q[:, :1].mean(1, keepdim=True) * 2.0     # first tile mostly anti-aligned with many queries
+    k[:, 300, :64] = q[:, 17, :64] * 5.0                  # late spike for one query, head 0
+    q, k, v = q.to(dtype), k.to(dtype), v.to(dtype)
+    out = ctx.attention(dev(ctx, q), dev(ctx, k), dev(ctx, v), heads, variant=variant)
+    assert_close(out, ref_attention(q, k, v, heads), dtype, scale=6.0, what=f"flash variant {variant}")
+
+
 def test_flash_attention_forced_rescale(ctx, dtype):
     """a key spike late in the sequence forces the online-softmax rescale branch with a large max jump."""
     g = torch.Generator().manual_seed(11)
