@@ -44,15 +44,22 @@ def main():
     ap.add_argument("--solver-mode", default="normal", choices=["normal", "fast"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--small", action="store_true", help="reduced-width smoke configuration (NOT the metric)")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl = RCCL over xGMI (default); gloo only for single-GPU plumbing tests")
+    ap.add_argument("--share-gpu0", action="store_true", help="TEST ONLY: every rank uses cuda:0 (1-GPU box, gloo backend)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.share_gpu0:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.dist_backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.set_grad_enabled(False)
     dtype = {"bf16": torch.bfloat16, "f16": torch.float16}[args.dtype]
@@ -115,7 +122,7 @@ def main():
     prof_u, prof_v = uctx.profile_end(), vctx.profile_end()
     if world > 1:
         import torch.distributed as dist
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([elapsed], device=dev if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     final = out[0] if isinstance(out, list) else out

@@ -657,6 +657,213 @@ flash_attn_v3_kernel(const AttnParams p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// flash_attn_v4_kernel: software-pipelined across key tiles.  One wave owns 32 query rows (128-row workgroups, 3 per
+// CU), keeps TWO score blocks live and, in steady state, issues
+//     phase 1:  QK^T MFMAs of tile t+1   beside   exp2 / pack / row-sum VALU of tile t
+//     phase 2:  PV   MFMAs of tile t     beside   row-max VALU of tile t+1 (+ the rare wave-uniform rescale)
+// so MFMA and VALU of the same wave overlap (~5.5 VALU per MFMA, the shadow one 32x32x16 MFMA offers) instead of running
+// QK^T -> softmax -> PV as one dependency chain (PMC of the baseline: matrix pipe 38 % busy, 46 % issue stalls).
+// Scale and running max ride in the MFMA through the augmented k-step (see v3); a second augmented slot adds -30000 to
+// keys past Nk, so the ragged key tail needs no select pass and no peeled tile.  K/V tiles: 3-slot LDS ring (48 KB).
+template <class T>
+STAR_GLOBAL void STAR_LAUNCH_BOUNDS(256, 2)
+flash_attn_v4_kernel(const AttnParams p) {
+  constexpr int QW = 32, QB = 128, KT = 64, TILE = KT * 128;
+  constexpr float RESCALE_THR = 8.0f;
+  char* smem = dyn_smem();   // [3][K tile | V tile]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h2 = lane >> 5, lq = lane & 31;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int bh = xcd + 8 * (slot / p.nqb);
+  const int qb = slot % p.nqb;
+  if (bh >= p.batch * p.heads) return;
+  const int b = bh / p.heads, hd = bh % p.heads;
+  const T* __restrict__ Qg = (const T*)p.Q + (size_t)b * p.bsq + hd * 64;
+  const T* __restrict__ Kg = (const T*)p.K + (size_t)b * p.bsk + hd * 64;
+  const T* __restrict__ Vg = (const T*)p.V + (size_t)b * p.bsv + hd * 64;
+  T* __restrict__ Og = (T*)p.O + (size_t)b * p.bso + hd * 64;
+
+  vec<T, 8> qf[4];
+  const int q_row = qb * QB + wave * QW + lq;
+  {
+    const int q = q_row < p.Nq ? q_row : p.Nq - 1;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const vec<T, 8> raw = *reinterpret_cast<const vec<T, 8>*>(Qg + (size_t)q * p.ldq + ks * 16 + h2 * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qf[ks][e] = from_f32<T>(to_f32<T>(raw[e]) * p.scale_log2e);
+    }
+  }
+  // augmented k-step: slot 0 carries -m_run (K side 1), slot 1 carries -30000 for keys >= Nk (K side 1 on those keys)
+  vec<T, 8> qaug;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) qaug[e] = from_f32<T>(0.f);
+  if (h2 == 0) qaug[1] = from_f32<T>(-30000.0f);
+
+  const int pos = tid & 7;
+  auto stage = [&](int t) {
+    char* kbuf = smem + (t % 3) * 2 * TILE;
+    char* vbuf = kbuf + TILE;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r = (j * 256 + tid) >> 3;
+      const int c = pos ^ ((r >> 1) & 7);
+      int key = t * KT + r;
+      if (key > p.Nk - 1) key = p.Nk - 1;
+      glds16(Kg + (size_t)key * p.ldk + c * 8, kbuf + (size_t)(j * 256 + wave * 64) * 16);
+      glds16(Vg + (size_t)key * p.ldv + c * 8, vbuf + (size_t)(j * 256 + wave * 64) * 16);
+    }
+  };
+
+  f32x16 oacc[2];
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[db][r] = 0.f;
+  float m_run = 0.f, l0 = 0.f, l1 = 0.f;
+  const int nt = (p.Nk + KT - 1) / KT;
+
+  // S^T of tile t (already relative to m_run, masked past Nk)
+  auto qk = [&](int t, f32x16 (&s)[2]) {
+    const char* kbuf = smem + (t % 3) * 2 * TILE;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      vec<T, 8> kaug;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) kaug[e] = from_f32<T>(0.f);
+      if (h2 == 0) {
+        kaug[0] = from_f32<T>(1.0f);
+        kaug[1] = from_f32<T>((t * KT + kb * 32 + lq >= p.Nk) ? 1.0f : 0.0f);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+      s[kb] = mfma32<T>(kaug, qaug, s[kb]);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        const vec<T, 8> kf = *reinterpret_cast<const vec<T, 8>*>(kbuf + swz_off(kb * 32 + lq, ks * 2 + h2));
+        s[kb] = mfma32<T>(kf, qf[ks], s[kb]);
+      }
+  };
+  // row max of a score block -> wave-uniform decision; on growth (or first tile) move the running max
+  auto decide = [&](f32x16 (&s)[2], bool force) {
+    float mx[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int kb = g >> 1, o = (g & 1) * 8;
+      const float a0 = fmaxf(fmaxf(s[kb][o], s[kb][o + 1]), s[kb][o + 2]);
+      const float a1 = fmaxf(fmaxf(s[kb][o + 3], s[kb][o + 4]), s[kb][o + 5]);
+      mx[g] = fmaxf(fmaxf(a0, a1), fmaxf(s[kb][o + 6], s[kb][o + 7]));
+    }
+    const float m_tile = pair_max(fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3])));
+    if (force || wave_any(m_tile > RESCALE_THR)) {
+      const float inc = force ? m_tile : fmaxf(m_tile, 0.f);
+      const float m_new = to_f32<T>(from_f32<T>(m_run + inc));
+      const float delta = m_new - m_run;
+      const float alpha = fast_exp2(-delta);
+      m_run = m_new;
+      l0 *= alpha; l1 *= alpha;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[kb][r] -= delta;
+      if (h2 == 0) qaug[0] = from_f32<T>(-m_new);
+    }
+  };
+  // one pipeline step: consumes s_cur (tile t), produces s_nxt (tile t+1)
+  auto step = [&](int t, f32x16 (&s_cur)[2], f32x16 (&s_nxt)[2], auto more_tag) {
+    constexpr bool more = decltype(more_tag)::value;   // steady state (true) is branch-free; the last tile is peeled
+    glds_wait();
+    block_sync();                      // tile t+1 has landed; every wave is done with the slot tile t+2 will overwrite
+    if constexpr (more) stage(t + 2 < nt ? t + 2 : nt - 1);   // past the end: harmless reload of the last tile into a free slot
+    // ---- phase 1: QK^T(t+1) MFMAs beside exp2 / pack / row sums of tile t
+    if constexpr (more) qk(t + 1, s_nxt);
+    vec<T, 8> pf[4];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        vec<T, 8> pk;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pk[e] = from_f32<T>(fast_exp2(s_cur[kb][8 * u + e]));
+#pragma unroll
+        for (int e = 0; e < 8; e += 4) {
+          vec<T, 2> a, b2;
+          a[0] = pk[e]; a[1] = pk[e + 1]; b2[0] = pk[e + 2]; b2[1] = pk[e + 3];
+          l0 = dot2_ones<T>(a, l0);
+          l1 = dot2_ones<T>(b2, l1);
+        }
+        pf[kb * 2 + u] = pk;
+      }
+#ifndef STAR_HOSTEMU
+    if constexpr (more) for (int i = 0; i < 10; ++i) { STAR_SCHED_GROUP(0x008, 1, 0); STAR_SCHED_GROUP(0x100, 1, 0); STAR_SCHED_GROUP(0x002, 7, 0); }
+#endif
+    // ---- phase 2: PV(t) MFMAs beside the row max of tile t+1
+    const char* vbuf = smem + (t % 3) * 2 * TILE + TILE;
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        const vec<T, 8> vf = load_vt_frag<T>(vbuf, tt * 16, db, lane);
+        oacc[db] = mfma32<T>(vf, pf[tt], oacc[db]);
+      }
+    if constexpr (more) decide(s_nxt, false);
+  };
+
+  // ---- prologue: tiles 0 and 1 in flight, S(0) computed, its max taken
+  f32x16 sa[2], sb[2];
+  stage(0);
+  if (nt > 1) stage(1);
+  glds_wait();
+  block_sync();
+  qk(0, sa);
+  decide(sa, true);
+  int t = 0;
+  for (; t + 2 < nt; t += 2) {         // tiles t and t+1 both have a successor
+    step(t, sa, sb, std::true_type{});
+    step(t + 1, sb, sa, std::true_type{});
+  }
+  if (t + 1 < nt) {                    // two tiles left
+    step(t, sa, sb, std::true_type{});
+    step(t + 1, sb, sa, std::false_type{});
+  } else {                             // one tile left
+    step(t, sa, sb, std::false_type{});
+  }
+
+  // ---- epilogue
+  {
+    const float l = pair_sum(l0 + l1);
+    const float inv = 1.0f / l;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        uint32_t w0[2], w1[2];
+#pragma unroll
+        for (int gg = 0; gg < 2; ++gg) {
+          vec<T, 4> o4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o4[e] = from_f32<T>(oacc[db][(2 * a + gg) * 4 + e] * inv);
+          u32x2 pk = __builtin_bit_cast(u32x2, o4);
+          if (gg == 0) { w0[0] = pk[0]; w0[1] = pk[1]; } else { w1[0] = pk[0]; w1[1] = pk[1]; }
+        }
+        const u32x2 x0 = permlane32_swap(w0[0], w1[0]);
+        const u32x2 x1 = permlane32_swap(w0[1], w1[1]);
+        u32x4 out;
+        out[0] = x0[0]; out[1] = x1[0]; out[2] = x0[1]; out[3] = x1[1];
+        if (q_row < p.Nq) *reinterpret_cast<u32x4*>(Og + (size_t)q_row * p.ldo + 32 * db + 16 * a + 8 * h2) = out;
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 struct TAttnParams {
   const void* Q; const void* K; const void* V; void* O;
   int ldq, ldk, ldv, ldo;   // row strides (elements) of the [F*HW, *] token matrices

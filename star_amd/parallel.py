@@ -103,6 +103,11 @@ class FrameSharder:
 def gather_frames(frames, group=None):
     """C1: all-gather of each rank's decoded clip [1, 3, F, H, W] -> list of world tensors (same shape on all ranks)."""
     world, _ = _world(group)
+    if dist.get_backend(group) == "gloo" and frames.is_cuda:   # plumbing tests on a 1-GPU box: stage through the host
+        host = frames.contiguous().cpu()
+        outs = [torch.empty_like(host) for _ in range(world)]
+        dist.all_gather(outs, host, group=group)
+        return [o.to(frames.device) for o in outs]
     outs = [torch.empty_like(frames) for _ in range(world)]
     dist.all_gather(outs, frames.contiguous(), group=group)
     return outs

@@ -142,8 +142,9 @@ def ref_attention(q, k, v, heads):
     return o.transpose(1, 2).reshape(B, -1, heads * 64)
 
 
-@pytest.mark.parametrize("B,heads,Nq,Nk", [(2, 2, 300, 300), (1, 5, 80, 80), (3, 1, 257, 64), (1, 2, 64, 1), (9, 1, 33, 130)])
-def test_flash_attention_self(ctx, dtype, B, heads, Nq, Nk):
+@pytest.mark.parametrize("variant", [2, 4])
+@pytest.mark.parametrize("B,heads,Nq,Nk", [(2, 2, 300, 300), (1, 5, 80, 80), (3, 1, 257, 64), (1, 2, 64, 1), (9, 1, 33, 130), (1, 1, 130, 129)])
+def test_flash_attention_self(ctx, dtype, B, heads, Nq, Nk, variant):
     """spatial self-attention (unet_v2v.py:472 -> :184) on a fused QKV buffer, ragged q/k tails."""
     g = torch.Generator().manual_seed(Nq + Nk)
     C = heads * 64
@@ -151,7 +152,7 @@ def test_flash_attention_self(ctx, dtype, B, heads, Nq, Nk):
     qkv = torch.randn(B, N, 3 * C, generator=g).to(dtype)
     q, k, v = qkv[:, :Nq, :C], qkv[:, :Nk, C:2 * C], qkv[:, :Nk, 2 * C:]
     qkvd = dev(ctx, qkv)
-    out = ctx.attention(qkvd[:, :Nq, :C], qkvd[:, :Nk, C:2 * C], qkvd[:, :Nk, 2 * C:], heads)
+    out = ctx.attention(qkvd[:, :Nq, :C], qkvd[:, :Nk, C:2 * C], qkvd[:, :Nk, 2 * C:], heads, variant=variant)
     assert_close(out, ref_attention(q, k, v, heads), dtype, what="flash self")
 
 
@@ -166,7 +167,7 @@ def test_flash_attention_cross_77(ctx, dtype):
     assert_close(out, ref_attention(q, kv[..., :128], kv[..., 128:], heads), dtype, what="flash cross")
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
 def test_flash_attention_variants_agree(ctx, dtype, variant):
     """all kernel variants (baseline / v2 / v3 with the augmented-k running max) against the fp32 reference, incl. a
     ragged key tail, strongly negative logits in tile 0 and a late spike that forces the rescale branch."""
