@@ -133,9 +133,14 @@ def main():
         evals = 14 if args.solver_mode == "fast" else args.denoise_steps
         a = prof_u["attn_self"]
         l0_flops = a["max_flops"]                       # the largest launches = the L0 layers (N = H*W of the padded latent)
-        roof = {"bound": "mfma", "kernel": "flash_attn_kernel (spatial self-attention, d=64)", "unit": "TFLOP/s",
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_attn_traffic.json")
+        if os.path.isfile(tpath) and not args.small and args.frames == 32:   # PMC pass of the same kernel at the same shape
+            traffic = json.load(open(tpath))["traffic_bytes_per_launch"]
+        roof = {"bound": "mfma", "kernel": "flash_attn_v3_kernel (spatial self-attention, d=64)", "unit": "TFLOP/s",
                 "achieved": (l0_flops / (a["max_flops_ms"] * 1e-3) / 1e12) if a["max_flops_ms"] else None,
-                "peak": PEAK_BF16_MFMA / 1e12, "traffic": None,
+                "peak": PEAK_BF16_MFMA / 1e12, "traffic": traffic,
+                "traffic_source": "profiles/r01_attn_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch)" if traffic else None,
                 "algorithmic_flops_per_launch": l0_flops, "avg_launch_ms": a["max_flops_ms"],
                 "all_self_attn_launches": {"launches": a["launches"], "ms": a["ms"], "TFLOP/s": a["flops"] / max(a["ms"], 1e-9) / 1e9}}
         roof["frac"] = roof["achieved"] / roof["peak"] if roof["achieved"] else None
