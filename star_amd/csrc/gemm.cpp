@@ -64,8 +64,6 @@ int op_gemm(Ctx* ctx, const GemmArgs& a) {
     if (a.N % 8 || a.ldc % 8 || ((a.epi & EPI_RES) && a.ldr % 8)) return ctx->fail("gemm: N, ldc (and ldr) must be multiples of 8");
   }
   if (a.M <= 0 || a.N <= 0) return 0;
-  const double taps = a.mode == A_PLAIN ? 1.0 : 1.0;
-  (void)taps;
   ProfScope ps(ctx, a.mode == A_PLAIN ? PK_GEMM : (a.mode == A_TCONV3 ? PK_TCONV : PK_CONV), 2.0 * a.M * (double)a.N * a.K,
                ((double)a.M * (a.mode == A_PLAIN ? a.K : a.Cin) + (double)a.M * ((a.epi & EPI_GEGLU) ? a.N / 2 : a.N)) * 2.0,
                a.M, a.N, a.K, a.epi);

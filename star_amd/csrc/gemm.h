@@ -180,24 +180,34 @@ gemm_kernel(const GemmParams p) {
     if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
     const char* abuf = smem + (kt & 1) * STAGE;
     const char* wbuf = abuf + A_STAGE;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      vec<T, 8> af[TM], wf[TN];
+    // fragments of k-step ks+1 are requested BEFORE the MFMAs of k-step ks (explicit register double buffer): the
+    // ~130-cycle LDS latency hides under the MFMA burst instead of being exposed four times per K tile
+    vec<T, 8> af[2][TM], wf[2][TN];
+    auto load_frags = [&](int ks, int slot) {
       const int c = ks * 2 + fhalf;
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int R = wm * WTM + i * 32 + frow;
-        af[i] = *reinterpret_cast<const vec<T, 8>*>(abuf + R * 128 + ((c ^ ((R >> 1) & 7)) << 4));
+        af[slot][i] = *reinterpret_cast<const vec<T, 8>*>(abuf + R * 128 + ((c ^ ((R >> 1) & 7)) << 4));
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int R = wn * WTN + j * 32 + frow;
-        wf[j] = *reinterpret_cast<const vec<T, 8>*>(wbuf + R * 128 + ((c ^ ((R >> 1) & 7)) << 4));
+        wf[slot][j] = *reinterpret_cast<const vec<T, 8>*>(wbuf + R * 128 + ((c ^ ((R >> 1) & 7)) << 4));
+      }
+    };
+    load_frags(0, 0);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (ks < 3) {
+        load_frags(ks + 1, (ks + 1) & 1);
+        // (pinning these reads above the MFMA burst with sched_barrier(0) was measured: conv 1000 -> 830 TF/s, GEMM neutral
+        //  -- profiles/r01_gemm_prefetch_fence_ab.txt -- so the scheduler is left free)
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = mfma32<T>(wf[j], af[i], acc[i][j]);
+        for (int j = 0; j < TN; ++j) acc[i][j] = mfma32<T>(wf[ks & 1][j], af[ks & 1][i], acc[i][j]);
     }
   }
 

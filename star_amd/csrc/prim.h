@@ -304,8 +304,10 @@ STAR_DEV bool wave_any(bool pred) {
 // compile-time scheduling hint (LLVM sched_group_barrier): emit `n` instructions of class `mask` next
 #ifdef STAR_HOSTEMU
 #define STAR_SCHED_GROUP(mask, n, id)
+#define STAR_SCHED_FENCE()
 #else
 #define STAR_SCHED_GROUP(mask, n, id) __builtin_amdgcn_sched_group_barrier((mask), (n), (id))
+#define STAR_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
 
 STAR_DEV float wave_sum(float v) {

@@ -32,10 +32,11 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--out", default="")
     ap.add_argument("--tiles", default="")
+    ap.add_argument("--lib", default="")
     args = ap.parse_args()
     dt = {"bf16": torch.bfloat16, "f16": torch.float16}[args.dtype]
     only = set(args.only.split(",")) if args.only else None
-    ctx = L.Context(0, dt)
+    ctx = L.Context(0, dt, L.Library(args.lib) if args.lib else None)
     dev = ctx.torch_device
     res = []
 
