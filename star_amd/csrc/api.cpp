@@ -52,6 +52,7 @@ void star_ctx_destroy(star_ctx* h) {
 const char* star_last_error(star_ctx* h) { return h ? h->c.err.c_str() : "null ctx"; }
 int star_set_stream(star_ctx* h, void* s) { h->c.stream = (hipStream_t)s; return 0; }
 int star_sync(star_ctx* h) {
+  if (h) rt::set_device(h->c.device);   // follow the context's device, not the caller's current one
   if (rt::stream_sync(h->c.stream)) return h->c.fail(std::string("sync failed: ") + rt::last_error_string());
   return 0;
 }
@@ -59,6 +60,7 @@ size_t star_pool_bytes(star_ctx* h) { return h->c.pool.total(); }
 size_t star_pool_peak_bytes(star_ctx* h) { return h->c.pool.peak(); }
 
 int star_gemm(star_ctx* h, const star_gemm_desc* d) {
+  if (h) rt::set_device(h->c.device);   // follow the context's device, not the caller's current one
   GemmArgs a;
   a.A = d->A; a.W = d->W; a.C = d->C; a.bias = d->bias; a.res = d->res;
   a.M = d->M; a.N = d->N; a.K = d->K; a.lda = d->lda; a.ldc = d->ldc; a.ldr = d->ldr;
@@ -70,6 +72,7 @@ int star_gemm(star_ctx* h, const star_gemm_desc* d) {
 
 
 int star_attn_fwd(star_ctx* h, const star_attn_desc* d) {
+  if (h) rt::set_device(h->c.device);   // follow the context's device, not the caller's current one
   AttnArgs a;
   a.Q = d->Q; a.K = d->K; a.V = d->V; a.O = d->O;
   a.ldq = d->ldq; a.ldk = d->ldk; a.ldv = d->ldv; a.ldo = d->ldo;
@@ -78,6 +81,7 @@ int star_attn_fwd(star_ctx* h, const star_attn_desc* d) {
   return op_flash_attn(&h->c, a);
 }
 int star_temporal_attn_fwd(star_ctx* h, const star_tattn_desc* d) {
+  if (h) rt::set_device(h->c.device);   // follow the context's device, not the caller's current one
   TAttnArgs a;
   a.Q = d->Q; a.K = d->K; a.V = d->V; a.O = d->O;
   a.ldq = d->ldq; a.ldk = d->ldk; a.ldv = d->ldv; a.ldo = d->ldo;
@@ -86,27 +90,39 @@ int star_temporal_attn_fwd(star_ctx* h, const star_tattn_desc* d) {
 }
 int star_group_norm(star_ctx* h, const void* x, int32_t ldx, void* y, int32_t ldy, const float* gamma,
                     const float* beta, int32_t rows, int32_t C, int32_t rows_per_stat, float eps, int32_t silu) {
+  if (h) rt::set_device(h->c.device);   // follow the context's device, not the caller's current one
   return op_group_norm(&h->c, x, ldx, y, ldy, gamma, beta, rows, C, rows_per_stat, eps, silu != 0);
 }
 int star_layer_norm(star_ctx* h, const void* x, int32_t ldx, void* y, int32_t ldy, const float* gamma,
                     const float* beta, int32_t rows, int32_t C, float eps, int32_t mode, const float* gate_w,
                     float* maps, int32_t H, int32_t W) {
+  if (h) rt::set_device(h->c.device);   // follow the context's device, not the caller's current one
   return op_layer_norm(&h->c, x, ldx, y, ldy, gamma, beta, rows, C, eps, mode, gate_w, maps, H, W);
 }
 int star_concat_add(star_ctx* h, const void* a, const void* b, const void* c, void* out, int32_t rows, int32_t C1, int32_t C2) {
+  if (h) rt::set_device(h->c.device);   // follow the context's device, not the caller's current one
   return op_concat_add(&h->c, a, b, c, out, rows, C1, C2);
 }
-int star_add(star_ctx* h, const void* a, const void* b, void* out, int64_t n) { return op_add(&h->c, a, b, out, n); }
+int star_add(star_ctx* h, const void* a, const void* b, void* out, int64_t n) {
+  if (h) rt::set_device(h->c.device);
+  return op_add(&h->c, a, b, out, n);
+}
 int star_stem_im2col(star_ctx* h, const float* latent, void* out, int32_t Cl, int32_t F, int32_t H, int32_t W) {
+  if (h) rt::set_device(h->c.device);   // follow the context's device, not the caller's current one
   return op_stem_im2col(&h->c, latent, out, Cl, F, H, W);
 }
 int star_rows_to_latent(star_ctx* h, const float* rows, float* out, int32_t Cl, int32_t ld, int64_t ntok) {
+  if (h) rt::set_device(h->c.device);   // follow the context's device, not the caller's current one
   return op_rows_to_latent(&h->c, rows, out, Cl, ld, ntok);
 }
 int star_gemv(star_ctx* h, const float* x, const void* W, const float* b, float* y, int32_t N, int32_t K, int32_t silu_in, int32_t silu_out) {
+  if (h) rt::set_device(h->c.device);   // follow the context's device, not the caller's current one
   return op_gemv(&h->c, x, W, b, y, N, K, silu_in != 0, silu_out != 0);
 }
-int star_cast(star_ctx* h, const float* x, void* y, int64_t n) { return op_cast(&h->c, x, y, n); }
+int star_cast(star_ctx* h, const float* x, void* y, int64_t n) {
+  if (h) rt::set_device(h->c.device);
+  return op_cast(&h->c, x, y, n);
+}
 
 
 int star_load_tensor(star_ctx* h, const char* name, const void* host, const int64_t* shape, int32_t ndim, int32_t dtype) {
@@ -123,6 +139,7 @@ int star_load_tensor(star_ctx* h, const char* name, const void* host, const int6
 }
 int star_clear_staged(star_ctx* h) { h->c.host_tensors.clear(); return 0; }
 int star_unet_build(star_ctx* h, const star_unet_config* c) {
+  if (h) rt::set_device(h->c.device);   // follow the context's device, not the caller's current one
   UNetCfg cfg;
   cfg.in_dim = c->in_dim; cfg.dim = c->dim; cfg.context_dim = c->context_dim; cfg.out_dim = c->out_dim;
   cfg.n_levels = c->n_levels;
@@ -134,15 +151,18 @@ int star_unet_build(star_ctx* h, const star_unet_config* c) {
   return unet_build(&h->c, cfg);
 }
 int star_unet_forward(star_ctx* h, const float* xt, int64_t t, const float* y, const float* hint, float* out, int32_t f, int32_t hh, int32_t w) {
+  if (h) rt::set_device(h->c.device);   // follow the context's device, not the caller's current one
   return unet_forward(&h->c, xt, (long long)t, y, hint, out, f, hh, w);
 }
 int star_module_run(star_ctx* h, int32_t kind, const char* prefix, int32_t cin, int32_t cout, int32_t heads, int32_t embed_dim,
                     int32_t context_dim, const void* x, const float* emb, const float* context, void* out, int32_t f, int32_t hh, int32_t w) {
+  if (h) rt::set_device(h->c.device);   // follow the context's device, not the caller's current one
   return module_run(&h->c, kind, prefix, cin, cout, heads, embed_dim, context_dim, x, emb, context, out, f, hh, w);
 }
 
 
 int star_vae_build(star_ctx* h, const star_vae_config* c) {
+  if (h) rt::set_device(h->c.device);   // follow the context's device, not the caller's current one
   VaeCfg cfg;
   cfg.in_ch = c->in_ch; cfg.out_ch = c->out_ch; cfg.latent = c->latent; cfg.n_blocks = c->n_blocks;
   for (int i = 0; i < 8; ++i) cfg.block_out[i] = c->block_out[i];
@@ -151,9 +171,16 @@ int star_vae_build(star_ctx* h, const star_vae_config* c) {
   for (int i = 0; i < cfg.n_blocks; ++i) if (cfg.block_out[i] % 64) return h->c.fail("vae_build: block_out channels must be multiples of 64");
   return vae_build(&h->c, cfg);
 }
-int star_vae_encode(star_ctx* h, const float* x, float* moments, int32_t n, int32_t H, int32_t W) { return vae_encode(&h->c, x, moments, n, H, W); }
-int star_vae_decode(star_ctx* h, const float* z, float* out, int32_t n, int32_t hh, int32_t w) { return vae_decode(&h->c, z, out, n, hh, w); }
+int star_vae_encode(star_ctx* h, const float* x, float* moments, int32_t n, int32_t H, int32_t W) {
+  if (h) rt::set_device(h->c.device);
+  return vae_encode(&h->c, x, moments, n, H, W);
+}
+int star_vae_decode(star_ctx* h, const float* z, float* out, int32_t n, int32_t hh, int32_t w) {
+  if (h) rt::set_device(h->c.device);
+  return vae_decode(&h->c, z, out, n, hh, w);
+}
 int star_softmax_rows(star_ctx* h, const float* s, int32_t lds, void* p, int32_t ldp, int32_t rows, int32_t n, float scale) {
+  if (h) rt::set_device(h->c.device);   // follow the context's device, not the caller's current one
   return op_softmax_rows(&h->c, s, lds, p, ldp, rows, n, scale);
 }
 
@@ -165,6 +192,7 @@ int star_profile_begin(star_ctx* h) {
   return 0;
 }
 int star_profile_end(star_ctx* h, star_prof_entry* out) {
+  if (h) rt::set_device(h->c.device);   // follow the context's device, not the caller's current one
   rt::stream_sync(h->c.stream);
   if (const char* path = getenv("STAR_PROF_DETAIL")) {   // per-launch records: kind, dims, ms
     if (FILE* f = fopen(path, "a")) {
