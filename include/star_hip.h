@@ -113,6 +113,12 @@ int star_unet_build(star_ctx* ctx, const star_unet_config* cfg);
  * y: fp32 device [77, context_dim]; t: the integer timestep. */
 int star_unet_forward(star_ctx* ctx, const float* xt, int64_t t, const float* y, const float* hint, float* out,
                       int32_t f, int32_t h, int32_t w);
+/* replaces: the TWO sequential denoiser calls of classifier-free guidance in GaussianDiffusion.denoise
+ * (diffusion_sdedit.py:81 cond, :88 uncond): same xt / t / hint, two text contexts.  Bit-identical to two
+ * star_unet_forward calls, but everything that does not depend on the text context (up to and including the
+ * self-attention of each net's first spatial transformer) is computed once. */
+int star_unet_forward_cfg(star_ctx* ctx, const float* xt, int64_t t, const float* y_cond, const float* y_uncond,
+                          const float* hint, float* out_cond, float* out_uncond, int32_t f, int32_t h, int32_t w);
 /* one reference module (ResBlock / SpatialTransformer / TemporalTransformer / Downsample / Upsample) built from
  * staged tensors `prefix.*`; kind: 0 res, 1 spatial, 2 temporal, 3 down, 4 up.  x/out: channels-last rows (ctx dtype) */
 int star_module_run(star_ctx* ctx, int32_t kind, const char* prefix, int32_t cin, int32_t cout, int32_t heads,

@@ -19,10 +19,12 @@ static int launch_flash(Ctx* ctx, const AttnArgs& a) {
   if (a.variant == 0) STAR_LAUNCH((flash_attn_kernel<T>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);
   else if (a.variant == 1) STAR_LAUNCH((flash_attn_v2_kernel<T>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);
   else if (a.variant == 2) STAR_LAUNCH((flash_attn_v3_kernel<T, 2>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);
-  else if (a.variant == 4) {   // software-pipelined, 128-row workgroups, 3 per CU
+  else if (a.variant == 4) {   // software-pipelined, 128-row workgroups
     p.nqb = (a.Nq + 127) / 128;
     const long long nblk4 = 8LL * p.nqb * ((BH + 7) / 8);
-    STAR_LAUNCH((flash_attn_v4_kernel<T>), dim3((unsigned)nblk4), dim3(256), (size_t)(3 * 16384), ctx->stream, p);
+    STAR_LAUNCH((flash_attn_v4_kernel<T, 1>), dim3((unsigned)nblk4), dim3(256), (size_t)(3 * 16384), ctx->stream, p);
+  } else if (a.variant == 5) {   // software-pipelined, 256-row workgroups, ONE wave per SIMD (512 registers)
+    STAR_LAUNCH((flash_attn_v4_kernel<T, 2>), dim3((unsigned)nblk), dim3(256), (size_t)(3 * 16384), ctx->stream, p);
   } else {   // 128-row workgroups, 4 waves per SIMD
     p.nqb = (a.Nq + 127) / 128;
     const long long nblk4 = 8LL * p.nqb * ((BH + 7) / 8);

@@ -665,10 +665,10 @@ flash_attn_v3_kernel(const AttnParams p) {
 // QK^T -> softmax -> PV as one dependency chain (PMC of the baseline: matrix pipe 38 % busy, 46 % issue stalls).
 // Scale and running max ride in the MFMA through the augmented k-step (see v3); a second augmented slot adds -30000 to
 // keys past Nk, so the ragged key tail needs no select pass and no peeled tile.  K/V tiles: 3-slot LDS ring (48 KB).
-template <class T>
-STAR_GLOBAL void STAR_LAUNCH_BOUNDS(256, 2)
+template <class T, int NQ>   // NQ 32-row query blocks per wave; NQ = 2 runs ONE wave per SIMD with the whole 512-entry register file
+STAR_GLOBAL void STAR_LAUNCH_BOUNDS(256, (NQ == 2 ? 1 : 2))
 flash_attn_v4_kernel(const AttnParams p) {
-  constexpr int QW = 32, QB = 128, KT = 64, TILE = KT * 128;
+  constexpr int QW = 32 * NQ, QB = 4 * QW, KT = 64, TILE = KT * 128;
   constexpr float RESCALE_THR = 8.0f;
   char* smem = dyn_smem();   // [3][K tile | V tile]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -684,22 +684,27 @@ flash_attn_v4_kernel(const AttnParams p) {
   const T* __restrict__ Vg = (const T*)p.V + (size_t)b * p.bsv + hd * 64;
   T* __restrict__ Og = (T*)p.O + (size_t)b * p.bso + hd * 64;
 
-  vec<T, 8> qf[4];
-  const int q_row = qb * QB + wave * QW + lq;
-  {
+  vec<T, 8> qf[NQ][4];
+  const int q_row0 = qb * QB + wave * QW + lq;
+#pragma unroll
+  for (int qi = 0; qi < NQ; ++qi) {
+    const int q_row = q_row0 + qi * 32;
     const int q = q_row < p.Nq ? q_row : p.Nq - 1;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const vec<T, 8> raw = *reinterpret_cast<const vec<T, 8>*>(Qg + (size_t)q * p.ldq + ks * 16 + h2 * 8);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) qf[ks][e] = from_f32<T>(to_f32<T>(raw[e]) * p.scale_log2e);
+      for (int e = 0; e < 8; ++e) qf[qi][ks][e] = from_f32<T>(to_f32<T>(raw[e]) * p.scale_log2e);
     }
   }
   // augmented k-step: slot 0 carries -m_run (K side 1), slot 1 carries -30000 for keys >= Nk (K side 1 on those keys)
-  vec<T, 8> qaug;
+  vec<T, 8> qaug[NQ];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) qaug[e] = from_f32<T>(0.f);
-  if (h2 == 0) qaug[1] = from_f32<T>(-30000.0f);
+  for (int qi = 0; qi < NQ; ++qi) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qaug[qi][e] = from_f32<T>(0.f);
+    if (h2 == 0) qaug[qi][1] = from_f32<T>(-30000.0f);
+  }
 
   const int pos = tid & 7;
   auto stage = [&](int t) {
@@ -716,16 +721,20 @@ flash_attn_v4_kernel(const AttnParams p) {
     }
   };
 
-  f32x16 oacc[2];
+  f32x16 oacc[NQ][2];
+  float m_run[NQ], l0[NQ], l1[NQ];
 #pragma unroll
-  for (int db = 0; db < 2; ++db)
+  for (int qi = 0; qi < NQ; ++qi) {
+    m_run[qi] = 0.f; l0[qi] = 0.f; l1[qi] = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) oacc[db][r] = 0.f;
-  float m_run = 0.f, l0 = 0.f, l1 = 0.f;
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[qi][db][r] = 0.f;
+  }
   const int nt = (p.Nk + KT - 1) / KT;
 
   // S^T of tile t (already relative to m_run, masked past Nk)
-  auto qk = [&](int t, f32x16 (&s)[2]) {
+  auto qk = [&](int t, f32x16 (&s)[NQ][2]) {
     const char* kbuf = smem + (t % 3) * 2 * TILE;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
@@ -737,73 +746,88 @@ flash_attn_v4_kernel(const AttnParams p) {
         kaug[1] = from_f32<T>((t * KT + kb * 32 + lq >= p.Nk) ? 1.0f : 0.0f);
       }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
-      s[kb] = mfma32<T>(kaug, qaug, s[kb]);
+      for (int qi = 0; qi < NQ; ++qi) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[qi][kb][r] = 0.f;
+        s[qi][kb] = mfma32<T>(kaug, qaug[qi], s[qi][kb]);
+      }
     }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
         const vec<T, 8> kf = *reinterpret_cast<const vec<T, 8>*>(kbuf + swz_off(kb * 32 + lq, ks * 2 + h2));
-        s[kb] = mfma32<T>(kf, qf[ks], s[kb]);
+#pragma unroll
+        for (int qi = 0; qi < NQ; ++qi) s[qi][kb] = mfma32<T>(kf, qf[qi][ks], s[qi][kb]);
       }
   };
   // row max of a score block -> wave-uniform decision; on growth (or first tile) move the running max
-  auto decide = [&](f32x16 (&s)[2], bool force) {
-    float mx[4];
+  auto decide = [&](f32x16 (&s)[NQ][2], bool force) {
+    float m_tile[NQ];
+    bool grow = false;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int kb = g >> 1, o = (g & 1) * 8;
-      const float a0 = fmaxf(fmaxf(s[kb][o], s[kb][o + 1]), s[kb][o + 2]);
-      const float a1 = fmaxf(fmaxf(s[kb][o + 3], s[kb][o + 4]), s[kb][o + 5]);
-      mx[g] = fmaxf(fmaxf(a0, a1), fmaxf(s[kb][o + 6], s[kb][o + 7]));
+    for (int qi = 0; qi < NQ; ++qi) {
+      float mx[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int kb = g >> 1, o = (g & 1) * 8;
+        const float a0 = fmaxf(fmaxf(s[qi][kb][o], s[qi][kb][o + 1]), s[qi][kb][o + 2]);
+        const float a1 = fmaxf(fmaxf(s[qi][kb][o + 3], s[qi][kb][o + 4]), s[qi][kb][o + 5]);
+        mx[g] = fmaxf(fmaxf(a0, a1), fmaxf(s[qi][kb][o + 6], s[qi][kb][o + 7]));
+      }
+      m_tile[qi] = pair_max(fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3])));
+      grow = grow || (m_tile[qi] > RESCALE_THR);
     }
-    const float m_tile = pair_max(fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3])));
-    if (force || wave_any(m_tile > RESCALE_THR)) {
-      const float inc = force ? m_tile : fmaxf(m_tile, 0.f);
-      const float m_new = to_f32<T>(from_f32<T>(m_run + inc));
-      const float delta = m_new - m_run;
-      const float alpha = fast_exp2(-delta);
-      m_run = m_new;
-      l0 *= alpha; l1 *= alpha;
+    if (force || wave_any(grow)) {
 #pragma unroll
-      for (int db = 0; db < 2; ++db)
+      for (int qi = 0; qi < NQ; ++qi) {
+        const float inc = force ? m_tile[qi] : fmaxf(m_tile[qi], 0.f);
+        const float m_new = to_f32<T>(from_f32<T>(m_run[qi] + inc));
+        const float delta = m_new - m_run[qi];
+        const float alpha = fast_exp2(-delta);
+        m_run[qi] = m_new;
+        l0[qi] *= alpha; l1[qi] *= alpha;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+        for (int db = 0; db < 2; ++db)
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
+          for (int r = 0; r < 16; ++r) oacc[qi][db][r] *= alpha;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[kb][r] -= delta;
-      if (h2 == 0) qaug[0] = from_f32<T>(-m_new);
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s[qi][kb][r] -= delta;
+        if (h2 == 0) qaug[qi][0] = from_f32<T>(-m_new);
+      }
     }
   };
   // one pipeline step: consumes s_cur (tile t), produces s_nxt (tile t+1)
-  auto step = [&](int t, f32x16 (&s_cur)[2], f32x16 (&s_nxt)[2], auto more_tag) {
+  auto step = [&](int t, f32x16 (&s_cur)[NQ][2], f32x16 (&s_nxt)[NQ][2], auto more_tag) {
     constexpr bool more = decltype(more_tag)::value;   // steady state (true) is branch-free; the last tile is peeled
     glds_wait();
     block_sync();                      // tile t+1 has landed; every wave is done with the slot tile t+2 will overwrite
     if constexpr (more) stage(t + 2 < nt ? t + 2 : nt - 1);   // past the end: harmless reload of the last tile into a free slot
     // ---- phase 1: QK^T(t+1) MFMAs beside exp2 / pack / row sums of tile t
     if constexpr (more) qk(t + 1, s_nxt);
-    vec<T, 8> pf[4];
+    vec<T, 8> pf[NQ][4];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+    for (int qi = 0; qi < NQ; ++qi)
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        vec<T, 8> pk;
+      for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) pk[e] = from_f32<T>(fast_exp2(s_cur[kb][8 * u + e]));
+        for (int u = 0; u < 2; ++u) {
+          vec<T, 8> pk;
 #pragma unroll
-        for (int e = 0; e < 8; e += 4) {
-          vec<T, 2> a, b2;
-          a[0] = pk[e]; a[1] = pk[e + 1]; b2[0] = pk[e + 2]; b2[1] = pk[e + 3];
-          l0 = dot2_ones<T>(a, l0);
-          l1 = dot2_ones<T>(b2, l1);
+          for (int e = 0; e < 8; ++e) pk[e] = from_f32<T>(fast_exp2(s_cur[qi][kb][8 * u + e]));
+#pragma unroll
+          for (int e = 0; e < 8; e += 4) {
+            vec<T, 2> a, b2;
+            a[0] = pk[e]; a[1] = pk[e + 1]; b2[0] = pk[e + 2]; b2[1] = pk[e + 3];
+            l0[qi] = dot2_ones<T>(a, l0[qi]);
+            l1[qi] = dot2_ones<T>(b2, l1[qi]);
+          }
+          pf[qi][kb * 2 + u] = pk;
         }
-        pf[kb * 2 + u] = pk;
-      }
 #ifndef STAR_HOSTEMU
-    if constexpr (more) for (int i = 0; i < 10; ++i) { STAR_SCHED_GROUP(0x008, 1, 0); STAR_SCHED_GROUP(0x100, 1, 0); STAR_SCHED_GROUP(0x002, 7, 0); }
+    if constexpr (more) for (int i = 0; i < 10 * NQ; ++i) { STAR_SCHED_GROUP(0x008, 1, 0); STAR_SCHED_GROUP(0x100, 1, 0); STAR_SCHED_GROUP(0x002, 7, 0); }
 #endif
     // ---- phase 2: PV(t) MFMAs beside the row max of tile t+1
     const char* vbuf = smem + (t % 3) * 2 * TILE + TILE;
@@ -812,13 +836,14 @@ flash_attn_v4_kernel(const AttnParams p) {
 #pragma unroll
       for (int db = 0; db < 2; ++db) {
         const vec<T, 8> vf = load_vt_frag<T>(vbuf, tt * 16, db, lane);
-        oacc[db] = mfma32<T>(vf, pf[tt], oacc[db]);
+#pragma unroll
+        for (int qi = 0; qi < NQ; ++qi) oacc[qi][db] = mfma32<T>(vf, pf[qi][tt], oacc[qi][db]);
       }
     if constexpr (more) decide(s_nxt, false);
   };
 
   // ---- prologue: tiles 0 and 1 in flight, S(0) computed, its max taken
-  f32x16 sa[2], sb[2];
+  f32x16 sa[NQ][2], sb[NQ][2];
   stage(0);
   if (nt > 1) stage(1);
   glds_wait();
@@ -838,8 +863,10 @@ flash_attn_v4_kernel(const AttnParams p) {
   }
 
   // ---- epilogue
-  {
-    const float l = pair_sum(l0 + l1);
+#pragma unroll
+  for (int qi = 0; qi < NQ; ++qi) {
+    const int q_row = q_row0 + qi * 32;
+    const float l = pair_sum(l0[qi] + l1[qi]);
     const float inv = 1.0f / l;
 #pragma unroll
     for (int db = 0; db < 2; ++db)
@@ -850,7 +877,7 @@ flash_attn_v4_kernel(const AttnParams p) {
         for (int gg = 0; gg < 2; ++gg) {
           vec<T, 4> o4;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o4[e] = from_f32<T>(oacc[db][(2 * a + gg) * 4 + e] * inv);
+          for (int e = 0; e < 4; ++e) o4[e] = from_f32<T>(oacc[qi][db][(2 * a + gg) * 4 + e] * inv);
           u32x2 pk = __builtin_bit_cast(u32x2, o4);
           if (gg == 0) { w0[0] = pk[0]; w0[1] = pk[1]; } else { w1[0] = pk[0]; w1[1] = pk[1]; }
         }

@@ -129,10 +129,14 @@ struct Fwd : Runner {
     gemm(h3.p(), inner, R, proj_out, out.p(), out.C, x_in.p(), x_in.C);
   }
 
-  // SpatialTransformer.forward + BasicTransformerBlock space branch (unet_v2v.py:297-317, 466-477)
-  Act spatial_transformer(const STW& s, Act x) {
+  // SpatialTransformer.forward + BasicTransformerBlock space branch (unet_v2v.py:297-317, 466-477), in two halves:
+  // st_self  = GroupNorm, proj_in, LIEM gate, LN1, QKV, self-attention, to_out (+res): does NOT depend on the text context;
+  // st_cross = LN2, cross-attention to the context, LN3, GEGLU FF, proj_out (+ x_in): one per guidance branch.
+  struct STMid { Act x_in, h1; };
+  STMid st_self(const STW& s, const Act& x) {
     const int R = rows(x), C = s.C, HW = x.H * x.W;
     const TBlockW& tb = s.tb;
+    STMid mid; mid.x_in = x;
     Act n = make(C, x.H, x.W);
     gn(x, s.norm, n, false, 1e-6f, false);
     Act h = make(C, x.H, x.W);
@@ -144,7 +148,7 @@ struct Fwd : Runner {
     maps.reset();
     // self attention over the H*W tokens of each frame
     Buf qkv(ctx, (size_t)R * 3 * C * es);
-    if (!qkv.p) { rc = ctx->fail("out of device memory (qkv)"); return x; }
+    if (!qkv.p) { rc = ctx->fail("out of device memory (qkv)"); return mid; }
     gemm(n.p(), C, R, tb.qkv1, qkv.p, 3 * C);
     {
       AttnArgs a;
@@ -155,15 +159,20 @@ struct Fwd : Runner {
       ok(op_flash_attn(ctx, a));
     }
     qkv.reset();
-    Act h1 = make(C, x.H, x.W);
-    gemm(n.p(), C, R, tb.out1, h1.p(), C, h.p(), C);
-    h.drop();
-    // cross attention to the text context (shared by all frames)
-    ln(h1.p(), n.p(), R, C, tb.n2);
+    mid.h1 = make(C, x.H, x.W);
+    gemm(n.p(), C, R, tb.out1, mid.h1.p(), C, h.p(), C);
+    return mid;
+  }
+  Act st_cross(const STW& s, const STMid& mid, const void* context_T) {
+    const Act& x = mid.x_in;
+    const int R = rows(x), C = s.C, HW = x.H * x.W;
+    const TBlockW& tb = s.tb;
+    Act n = make(C, x.H, x.W);
+    ln(mid.h1.p(), n.p(), R, C, tb.n2);
     Act q2 = make(C, x.H, x.W);
     gemm(n.p(), C, R, tb.q2, q2.p(), C);
     Buf kv(ctx, (size_t)77 * 2 * C * es);
-    gemm(context, ctx_dim, 77, tb.kv2, kv.p, 2 * C);
+    gemm(context_T, ctx_dim, 77, tb.kv2, kv.p, 2 * C);
     {
       AttnArgs a;
       a.Q = q2.p(); a.K = kv.p; a.V = (char*)kv.p + (size_t)C * es; a.O = n.p();
@@ -174,11 +183,15 @@ struct Fwd : Runner {
     }
     q2.drop(); kv.reset();
     Act h2 = make(C, x.H, x.W);
-    gemm(n.p(), C, R, tb.out2, h2.p(), C, h1.p(), C);
-    h1.drop(); n.drop();
+    gemm(n.p(), C, R, tb.out2, h2.p(), C, mid.h1.p(), C);
+    n.drop();
     Act out = make(C, x.H, x.W);
     ff_and_out(tb, h2, R, C, s.proj_out, x, out);
     return out;
+  }
+  Act spatial_transformer(const STW& s, Act x) {
+    STMid mid = st_self(s, x);
+    return st_cross(s, mid, context);
   }
 
   // TemporalTransformer.forward + BasicTransformerBlock temp branch (unet_v2v.py:1034-1092, 479-490)
@@ -220,6 +233,36 @@ struct Fwd : Runner {
   Act up(const ConvW& c, Act x) {     // Upsample: nearest x2, rows [1:-1], conv 3x3 (unet_v2v.py:556-567)
     Act y = make(c.C, 2 * x.H - 2, 2 * x.W);
     conv3x3(x, c.conv, y, A_CONV3X3_UP, 1, 1, 1, nullptr);
+    return y;
+  }
+  // ---- classifier-free-guidance pair: up to two guidance branches (cond / uncond text context) share every activation
+  // that does not depend on the context, i.e. everything up to and including the self-attention of the FIRST spatial
+  // transformer of each net (stem conv, stem temporal transformer, first ResBlock, 28 ms of L0 self-attention ...).
+  struct PA { Act a[2]; bool same = true; };
+  int nb = 1;
+  const void* contexts[2] = {nullptr, nullptr};
+  PA run(const Net& net, const Mod& m, PA x) {
+    PA y;
+    if (m.kind == M_ST) {
+      const STW& st = net.st[m.idx];
+      if (x.same) {
+        STMid mid = st_self(st, x.a[0]);
+        for (int b = 0; b < nb; ++b) y.a[b] = st_cross(st, mid, contexts[b]);
+      } else {
+        for (int b = 0; b < nb; ++b) { STMid mid = st_self(st, x.a[b]); y.a[b] = st_cross(st, mid, contexts[b]); }
+      }
+      y.same = (nb == 1);
+      if (nb == 1) y.a[1] = y.a[0];
+      return y;
+    }
+    if (x.same) {
+      y.a[0] = run(net, m, x.a[0]);
+      y.a[1] = y.a[0];
+      y.same = true;
+    } else {
+      for (int b = 0; b < nb; ++b) y.a[b] = run(net, m, x.a[b]);
+      y.same = false;
+    }
     return y;
   }
   Act run(const Net& net, const Mod& m, Act x) {
@@ -345,8 +388,10 @@ static int time_embedding(Ctx* ctx, const Net& net, long long t, int dim, int E,
   return op_gemv(ctx, tmp_mid.as<float>(), net.time2.w.p, (const float*)net.time2.b.p, out, E, E, false, false);
 }
 
-int unet_forward(Ctx* ctx, const float* xt, long long t, const float* y, const float* hint, float* out, int F, int H, int W) {
+int unet_forward_n(Ctx* ctx, const float* xt, long long t, const float* const* ys, const float* hint, float* const* outs, int nb,
+                   int F, int H, int W) {
   if (!ctx->unet) return ctx->fail("unet_forward: no model built (star_unet_build)");
+  if (nb < 1 || nb > 2) return ctx->fail("unet_forward: 1 or 2 guidance branches");
   const UNetModel& M = *ctx->unet;
   const UNetCfg& cfg = M.cfg;
   if (F < 1 || F > 64) return ctx->fail("unet_forward: 1..64 frames per chunk");
@@ -357,11 +402,16 @@ int unet_forward(Ctx* ctx, const float* xt, long long t, const float* y, const f
     if (h != H || w != W) return ctx->fail("unet_forward: illegal latent size (need H = 2 mod 8, W = 0 mod 8)");
   }
   Fwd f; f.ctx = ctx; f.F = F; f.es = ctx->esize(); f.ctx_dim = cfg.context_dim; f.embed_dim = cfg.embed_dim();
+  f.nb = nb;
   const int E = cfg.embed_dim();
   const long long tok = (long long)F * H * W;
-  Buf ctxT(ctx, (size_t)77 * cfg.context_dim * f.es);
-  if (op_cast(ctx, y, ctxT.p, (long long)77 * cfg.context_dim)) return 1;
-  f.context = ctxT.p;
+  Buf ctxT[2];
+  for (int b = 0; b < nb; ++b) {
+    ctxT[b] = Buf(ctx, (size_t)77 * cfg.context_dim * f.es);
+    if (op_cast(ctx, ys[b], ctxT[b].p, (long long)77 * cfg.context_dim)) return 1;
+    f.contexts[b] = ctxT[b].p;
+  }
+  f.context = f.contexts[0];
   Buf emb_main(ctx, (size_t)E * 4), emb_ctrl(ctx, (size_t)E * 4), t_in(ctx, (size_t)cfg.dim * 4), t_mid(ctx, (size_t)E * 4);
   if (time_embedding(ctx, M.main, t, cfg.dim, E, t_in, t_mid, emb_main.as<float>())) return 1;
   if (time_embedding(ctx, M.control, t, cfg.dim, E, t_in, t_mid, emb_ctrl.as<float>())) return 1;
@@ -371,70 +421,104 @@ int unet_forward(Ctx* ctx, const float* xt, long long t, const float* y, const f
   if (!xcols.p || !hcols.p) return ctx->fail("out of device memory");
   if (op_stem_im2col(ctx, xt, xcols.p, cfg.in_dim, F, H, W)) return 1;
   if (op_stem_im2col(ctx, hint, hcols.p, 4, F, H, W)) return 1;
+  using PA = Fwd::PA;
+  auto both = [&](const Act& a) { PA p; p.a[0] = a; p.a[1] = a; p.same = true; return p; };
+  // y = zero_conv(x) per branch (shared while the branches still coincide)
+  auto lin = [&](const PA& x, const LinW& w) {
+    PA z;
+    for (int b = 0; b < (x.same ? 1 : nb); ++b) {
+      z.a[b] = f.make(x.a[b].C, x.a[b].H, x.a[b].W);
+      f.gemm(x.a[b].p(), x.a[b].C, f.rows(x.a[b]), w, z.a[b].p(), x.a[b].C);
+    }
+    if (x.same) z.a[1] = z.a[0];
+    z.same = x.same;
+    return z;
+  };
 
   // ---------------- VideoControlNet (unet_v2v.py:2134-2206)
-  std::vector<Act> control;
+  std::vector<PA> control;
   {
     const Net& net = M.control;
     f.emb = emb_ctrl.as<float>();
     Act hc = f.make(cfg.dim, H, W);
     f.gemm(hcols.p, 64, (int)tok, net.hint, hc.p(), cfg.dim);
     hcols.reset();
-    Act x = f.make(cfg.dim, H, W);
-    f.gemm(xcols.p, 64, (int)tok, net.stem, x.p(), cfg.dim, hc.p(), cfg.dim);   // stem conv + hint (added before the stem TT, :2190-2194)
+    Act x0 = f.make(cfg.dim, H, W);
+    f.gemm(xcols.p, 64, (int)tok, net.stem, x0.p(), cfg.dim, hc.p(), cfg.dim);   // stem conv + hint (added before the stem TT, :2190-2194)
     hc.drop();
+    PA x = both(x0);
+    x0.drop();
     for (size_t bi = 0; bi < net.input_blocks.size(); ++bi) {
       for (const Mod& m : net.input_blocks[bi]) x = f.run(net, m, std::move(x));
       if (f.rc) return f.rc;
-      Act z = f.make(x.C, x.H, x.W);
-      f.gemm(x.p(), x.C, f.rows(x), net.zero_convs[bi], z.p(), x.C);
-      control.push_back(std::move(z));
+      control.push_back(lin(x, net.zero_convs[bi]));
     }
     for (const Mod& m : net.middle) x = f.run(net, m, std::move(x));
     if (f.rc) return f.rc;
-    Act z = f.make(x.C, x.H, x.W);
-    f.gemm(x.p(), x.C, f.rows(x), net.middle_out, z.p(), x.C);
-    control.push_back(std::move(z));
+    control.push_back(lin(x, net.middle_out));
   }
   // ---------------- main UNet (unet_v2v.py:1765-1808)
   const Net& net = M.main;
   f.emb = emb_main.as<float>();
-  std::vector<Act> xs;
-  Act x = f.make(cfg.dim, H, W);
-  f.gemm(xcols.p, 64, (int)tok, net.stem, x.p(), cfg.dim);
-  xcols.reset();
+  std::vector<PA> xs;
+  PA x;
+  {
+    Act x0 = f.make(cfg.dim, H, W);
+    f.gemm(xcols.p, 64, (int)tok, net.stem, x0.p(), cfg.dim);
+    xcols.reset();
+    x = both(x0);
+  }
   for (size_t bi = 0; bi < net.input_blocks.size(); ++bi) {
     for (const Mod& m : net.input_blocks[bi]) x = f.run(net, m, std::move(x));
     if (f.rc) return f.rc;
-    xs.push_back(x);   // skip connection shares the buffer
+    xs.push_back(x);   // skip connection shares the buffer(s)
   }
   for (const Mod& m : net.middle) x = f.run(net, m, std::move(x));
   if (f.rc) return f.rc;
   {
-    Act s = f.make(x.C, x.H, x.W);
-    f.ok(op_add(ctx, control.back().p(), x.p(), s.p(), (long long)f.rows(x) * x.C));
+    PA& ctl = control.back();
+    PA s2;
+    s2.same = x.same && ctl.same;
+    for (int b = 0; b < (s2.same ? 1 : nb); ++b) {
+      s2.a[b] = f.make(x.a[b].C, x.a[b].H, x.a[b].W);
+      f.ok(op_add(ctx, ctl.a[b].p(), x.a[b].p(), s2.a[b].p(), (long long)f.rows(x.a[b]) * x.a[b].C));
+    }
+    if (s2.same) s2.a[1] = s2.a[0];
     control.pop_back();
-    x = std::move(s);
+    x = std::move(s2);
   }
   for (size_t bi = 0; bi < net.output_blocks.size(); ++bi) {
-    Act& skip = xs.back(); Act& ctl = control.back();
-    Act cat = f.make(x.C + skip.C, x.H, x.W);
-    if (skip.H != x.H || skip.W != x.W) return ctx->fail("unet_forward: skip shape mismatch");
-    f.ok(op_concat_add(ctx, x.p(), skip.p(), ctl.p(), cat.p(), f.rows(x), x.C, skip.C));
+    PA& skip = xs.back(); PA& ctl = control.back();
+    PA cat;
+    cat.same = x.same && skip.same && ctl.same;
+    for (int b = 0; b < (cat.same ? 1 : nb); ++b) {
+      if (skip.a[b].H != x.a[b].H || skip.a[b].W != x.a[b].W) return ctx->fail("unet_forward: skip shape mismatch");
+      cat.a[b] = f.make(x.a[b].C + skip.a[b].C, x.a[b].H, x.a[b].W);
+      f.ok(op_concat_add(ctx, x.a[b].p(), skip.a[b].p(), ctl.a[b].p(), cat.a[b].p(), f.rows(x.a[b]), x.a[b].C, skip.a[b].C));
+    }
+    if (cat.same) cat.a[1] = cat.a[0];
     xs.pop_back(); control.pop_back();
     x = std::move(cat);
     for (const Mod& m : net.output_blocks[bi]) x = f.run(net, m, std::move(x));
     if (f.rc) return f.rc;
   }
   // head: GN + SiLU + conv 3x3 -> out_dim, fp32 rows, then back to [1, C, F, H, W]
-  Act n = f.make(x.C, x.H, x.W);
-  f.gn(x, net.out_norm, n, false, 1e-5f, true);
-  x.drop();
-  Buf rowsf(ctx, (size_t)tok * 8 * 4);
-  Act dummy; dummy.C = 8; dummy.H = H; dummy.W = W;
-  f.conv3x3(n, net.out_conv, dummy, A_CONV3X3, 1, 1, 1, nullptr, nullptr, EPI_OUT_F32, rowsf.p, 8);
-  f.ok(op_rows_to_latent(ctx, rowsf.as<float>(), out, cfg.out_dim, 8, tok));
+  for (int b = 0; b < nb; ++b) {
+    const Act& xb = x.a[x.same ? 0 : b];
+    Act n = f.make(xb.C, xb.H, xb.W);
+    f.gn(xb, net.out_norm, n, false, 1e-5f, true);
+    Buf rowsf(ctx, (size_t)tok * 8 * 4);
+    Act dummy; dummy.C = 8; dummy.H = H; dummy.W = W;
+    f.conv3x3(n, net.out_conv, dummy, A_CONV3X3, 1, 1, 1, nullptr, nullptr, EPI_OUT_F32, rowsf.p, 8);
+    f.ok(op_rows_to_latent(ctx, rowsf.as<float>(), outs[b], cfg.out_dim, 8, tok));
+  }
   return f.rc;
+}
+
+int unet_forward(Ctx* ctx, const float* xt, long long t, const float* y, const float* hint, float* out, int F, int H, int W) {
+  const float* ys[1] = {y};
+  float* outs[1] = {out};
+  return unet_forward_n(ctx, xt, t, ys, hint, outs, 1, F, H, W);
 }
 
 int module_run(Ctx* ctx, int kind, const char* prefix, int cin, int cout, int heads, int embed_dim, int context_dim,

@@ -42,11 +42,18 @@ class GaussianDiffusion:
         else:
             cond = {**model_kwargs[0], **model_kwargs[2]}
             unc = {**model_kwargs[1], **model_kwargs[2]}
-            y_out = model(xt, t=t, **cond)
+            pair = getattr(model, "forward_cfg_pair", None) if guide_scale != 1.0 else None
+            if pair is not None:
+                # same two evaluations as the reference's sequential calls (bit-identical), sharing the part of the
+                # denoiser that does not see the text context (star_unet_forward_cfg)
+                y_out, u_out = pair(xt, t, cond.pop("y"), unc.pop("y"), **cond)
+            else:
+                y_out = model(xt, t=t, **cond)
             if guide_scale == 1.0:
                 out = y_out
             else:
-                u_out = model(xt, t=t, **unc)
+                if pair is None:
+                    u_out = model(xt, t=t, **unc)
                 out = u_out + guide_scale * (y_out - u_out)
                 if guide_rescale is not None:
                     ratio = (y_out.flatten(1).std(dim=1) / (out.flatten(1).std(dim=1) + 1e-12)).view((-1,) + (1,) * (y_out.ndim - 1))

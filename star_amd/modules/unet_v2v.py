@@ -29,6 +29,7 @@ def _bind(lib):
     lib.load_tensor = L._sig(c, "star_load_tensor", i32, vp, ctypes.c_char_p, vp, ctypes.POINTER(i64), i32, i32)
     lib.unet_build = L._sig(c, "star_unet_build", i32, vp, ctypes.POINTER(UNetConfigC))
     lib.unet_forward = L._sig(c, "star_unet_forward", i32, vp, vp, i64, vp, vp, vp, i32, i32, i32)
+    lib.unet_forward_cfg = L._sig(c, "star_unet_forward_cfg", i32, vp, vp, i64, vp, vp, vp, vp, vp, i32, i32, i32)
     lib.module_run = L._sig(c, "star_module_run", i32, vp, i32, ctypes.c_char_p, i32, i32, i32, i32, i32, vp, vp, vp, vp, i32, i32, i32)
     lib.clear_staged = L._sig(c, "star_clear_staged", i32, vp)
     lib._unet_bound = True
@@ -160,6 +161,36 @@ class ControlledV2VUNet:
         ctx._check(ctx.lib.unet_forward(ctx.h, L._ptr(xf), tt, L._ptr(yf), L._ptr(hf), L._ptr(out), f, h, w), "unet_forward")
         self.batch = b
         return out if x.dtype == torch.float32 else out.to(x.dtype)
+
+
+def _cfg_pair(self, x, t, y_cond, y_uncond, hint=None, hint_chunk=None, **unused):
+    """Both classifier-free-guidance forwards of one denoise step (diffusion_sdedit.py:81,88) in one call:
+    -> (y_out, u_out), bit-identical to two __call__s; the context-independent prefix of both nets runs once."""
+    if self.ctx is None:
+        raise L.StarError("ControlledV2VUNet: load_state_dict first")
+    if hint_chunk is not None:
+        hint = hint_chunk
+    b, c, f, h, w = x.shape
+    if b != 1:
+        raise L.StarError("the reference always calls the denoiser with batch 1 (diffusion_sdedit.py:81,88)")
+    ctx = self.ctx
+    ctx.use_current_stream()
+    dev = ctx.torch_device
+    xf = x.to(device=dev, dtype=torch.float32).contiguous()
+    hf = hint.to(device=dev, dtype=torch.float32).contiguous()
+    yc = y_cond.to(device=dev, dtype=torch.float32).reshape(77, self.cfg.context_dim).contiguous()
+    yu = y_uncond.to(device=dev, dtype=torch.float32).reshape(77, self.cfg.context_dim).contiguous()
+    tt = int(t.reshape(-1)[0]) if torch.is_tensor(t) else int(t)
+    oc = torch.empty(1, self.cfg.out_dim, f, h, w, dtype=torch.float32, device=dev)
+    ou = torch.empty_like(oc)
+    ctx._check(ctx.lib.unet_forward_cfg(ctx.h, L._ptr(xf), tt, L._ptr(yc), L._ptr(yu), L._ptr(hf), L._ptr(oc), L._ptr(ou), f, h, w),
+               "unet_forward_cfg")
+    if x.dtype != torch.float32:
+        oc, ou = oc.to(x.dtype), ou.to(x.dtype)
+    return oc, ou
+
+
+ControlledV2VUNet.forward_cfg_pair = _cfg_pair
 
 
 def run_module(ctx, kind, sd, prefix, x_nchw, emb=None, context=None, heads=1, cout=None):

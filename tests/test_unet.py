@@ -123,6 +123,19 @@ def test_full_unet_matches_reference_golden():
     assert e < REL_RMS[torch.float16][1], (e, psnr(out, gold["out"]))
 
 
+def test_cfg_pair_is_bit_identical_to_two_forwards(backend, request):
+    """star_unet_forward_cfg shares the context-independent prefix of both nets; results must equal two plain calls."""
+    net = _small_model(backend, torch.float16, request)
+    dev = net.ctx.torch_device
+    x, t, y, hint = unet_inputs(SMALL_TEST_CONFIG, 1 if backend == "emu" else 5, 10, 8, 11)
+    y2 = torch.randn(y.shape, generator=torch.Generator().manual_seed(12))
+    a = net(x.to(dev), t=t, y=y.to(dev), hint=hint.to(dev))
+    b = net(x.to(dev), t=t, y=y2.to(dev), hint=hint.to(dev))
+    pa, pb = net.forward_cfg_pair(x.to(dev), t, y.to(dev), y2.to(dev), hint=hint.to(dev))
+    assert torch.equal(a, pa) and torch.equal(b, pb)
+    assert not torch.equal(pa, pb)
+
+
 def test_illegal_latent_size_is_rejected(backend, request):
     from star_amd.lib import StarError
     net = _small_model(backend, torch.float16, request)

@@ -46,6 +46,13 @@ for _ in range(a.reps):
 torch.cuda.synchronize()
 wall = (time.perf_counter() - t0) / a.reps
 prof = net.ctx.profile_end()
+y2 = torch.randn(1, 77, 1024, generator=g).cuda()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(a.reps):
+    net.forward_cfg_pair(x, t, y, y2, hint=hint)
+torch.cuda.synchronize()
+print(f"CFG pair (2 branches, shared prefix) wall {(time.perf_counter() - t0) / a.reps * 1e3:.1f} ms vs 2 x single {2 * wall * 1e3:.1f} ms")
 print(f"forward wall {wall * 1e3:.1f} ms; sum of kernel ms {sum(v['ms'] for v in prof.values()) / a.reps:.1f}")
 agg = collections.OrderedDict()
 for line in open(path):
