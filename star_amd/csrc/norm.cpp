@@ -15,21 +15,21 @@ template <class T>
 static int gn_t(Ctx* ctx, const void* x, int ldx, void* y, int ldy, const float* gamma, const float* beta,
                 int rows, int C, int rows_per_stat, float eps, bool silu) {
   const int nstat = rows / rows_per_stat;
-  Buf sums(ctx, (size_t)nstat * 64 * sizeof(double));
-  Buf ab(ctx, (size_t)nstat * C * 2 * sizeof(float));
-  if (!sums.p || !ab.p) return ctx->fail("group_norm: out of device memory");
-  rt::memset_async(sums.p, 0, (size_t)nstat * 64 * sizeof(double), ctx->stream);
   const int CC8 = C / 8;
   int RL = 256 / CC8; if (RL < 1) RL = 1;
   const int nthreads = CC8 * RL;
   // slab: enough rows per block to amortise the reduction, enough blocks to fill the chip
   int slab = 256;
   while ((long long)((rows_per_stat + slab - 1) / slab) * nstat < 1024 && slab > 32) slab >>= 1;
-  GnStatsParams sp{x, ldx, C, rows_per_stat, slab, sums.as<double>()};
-  dim3 grid((unsigned)((rows_per_stat + slab - 1) / slab), (unsigned)nstat);
-  STAR_LAUNCH((gn_stats_kernel<T>), grid, dim3(nthreads), (size_t)256, ctx->stream, sp);
-  GnFinalizeParams fp{sums.as<double>(), gamma, beta, ab.as<float>(), C, nstat, (double)rows_per_stat * (C / 32), eps};
-  STAR_LAUNCH(gn_finalize_kernel, dim3((unsigned)((nstat * C + 255) / 256)), dim3(256), (size_t)0, ctx->stream, fp);
+  const int nslab = (rows_per_stat + slab - 1) / slab;
+  Buf partial(ctx, (size_t)nstat * nslab * 64 * sizeof(double));
+  Buf ab(ctx, (size_t)nstat * C * 2 * sizeof(float));
+  if (!partial.p || !ab.p) return ctx->fail("group_norm: out of device memory");
+  GnStatsParams sp{x, ldx, C, rows_per_stat, slab, partial.as<double>()};
+  dim3 grid((unsigned)nslab, (unsigned)nstat);
+  STAR_LAUNCH((gn_stats_kernel<T>), grid, dim3(nthreads), (size_t)nthreads * 64, ctx->stream, sp);
+  GnFinalizeParams fp{partial.as<double>(), gamma, beta, ab.as<float>(), C, nstat, nslab, (double)rows_per_stat * (C / 32), eps};
+  STAR_LAUNCH(gn_finalize_kernel, dim3((unsigned)((nstat * 32 + 3) / 4)), dim3(256), (size_t)0, ctx->stream, fp);
   GnApplyParams ap{x, y, ab.as<float>(), ldx, ldy, C, rows, rows_per_stat, silu ? 1 : 0};
   STAR_LAUNCH((gn_apply_kernel<T>), dim3(ew_grid((long long)rows * CC8)), dim3(256), (size_t)0, ctx->stream, ap);
   return 0;

@@ -16,11 +16,14 @@ STAR_DEV float sigmoid_f(float x) { return fast_rcp(1.0f + fast_exp2(-1.44269504
 // reference: nn.GroupNorm(32, C) on (b f) c h w  [stats per frame]  unet_v2v.py:610,635,268
 //            nn.GroupNorm(32, C) on  b c f h w   [stats over the whole chunk] unet_v2v.py:1210-1219,1002
 struct GnStatsParams {
-  const void* x; int ld; int C; int rows_per_stat; int slab; double* sums;  // sums[nstat][32][2]
+  const void* x; int ld; int C; int rows_per_stat; int slab; double* partial;  // partial[nstat][nslab][32][2]
 };
+// Deterministic by construction (fixed reduction order, no atomics): every launch gives bit-identical statistics, hence a
+// bit-reproducible forward.  Per block: threads own a fixed 8-channel chunk and stride over the slab's rows; the per-thread
+// sums go through LDS and are reduced in index order by one thread per group.
 template <class T>
 STAR_GLOBAL void gn_stats_kernel(const GnStatsParams p) {
-  float* gs = reinterpret_cast<float*>(dyn_smem());  // [32][2]
+  float* ts = reinterpret_cast<float*>(dyn_smem());  // [nthreads][16]: s[8] | ss[8]
   const int t = threadIdx.x;
   const int CC8 = p.C >> 3;
   const int RL = blockDim.x / CC8;
@@ -29,8 +32,6 @@ STAR_GLOBAL void gn_stats_kernel(const GnStatsParams p) {
   const int r0 = blockIdx.x * p.slab;
   int r1 = r0 + p.slab;
   if (r1 > p.rows_per_stat) r1 = p.rows_per_stat;
-  if (t < 64) gs[t] = 0.f;
-  block_sync();
   float s[8], ss[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; }
@@ -41,38 +42,60 @@ STAR_GLOBAL void gn_stats_kernel(const GnStatsParams p) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) { const float f = to_f32<T>(v[e]); s[e] += f; ss[e] += f * f; }
     }
-    const int cg = p.C >> 5;
-    int g = (cc * 8) / cg;
-    float a = 0.f, b = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int ge = (cc * 8 + e) / cg;
-      if (ge != g) { atomic_add(&gs[2 * g], a); atomic_add(&gs[2 * g + 1], b); a = 0.f; b = 0.f; g = ge; }
-      a += s[e]; b += ss[e];
-    }
-    atomic_add(&gs[2 * g], a); atomic_add(&gs[2 * g + 1], b);
   }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { ts[t * 16 + e] = s[e]; ts[t * 16 + 8 + e] = ss[e]; }
   block_sync();
-  if (t < 64) atomic_add(&p.sums[(size_t)stat * 64 + t], (double)gs[t]);
+  if (t < 32) {   // group t: channels [t*cg, (t+1)*cg), all row lanes, fixed order
+    const int cg = p.C >> 5;
+    double a = 0.0, b = 0.0;
+    for (int c = t * cg; c < (t + 1) * cg; ++c) {
+      const int ccx = c >> 3, e = c & 7;
+      for (int l = 0; l < RL; ++l) {
+        const float* q = ts + (l * CC8 + ccx) * 16;
+        a += (double)q[e];
+        b += (double)q[8 + e];
+      }
+    }
+    double* out = p.partial + (((size_t)stat * gridDim.x + blockIdx.x) * 32 + t) * 2;
+    out[0] = a;
+    out[1] = b;
+  }
 }
 
-// sums -> per-(stat, channel) affine (a, b): y = x*a + b
+// partial sums -> per-(stat, channel) affine (a, b): y = x*a + b.  One wavefront per (stat, group): lanes stride over the
+// slabs in order, then a fixed shuffle tree.
 struct GnFinalizeParams {
-  const double* sums; const float* gamma; const float* beta; float* ab;  // ab[nstat][C][2]
-  int C; int nstat; double count; float eps;
+  const double* partial; const float* gamma; const float* beta; float* ab;  // ab[nstat][C][2]
+  int C; int nstat; int nslab; double count; float eps;
 };
 STAR_GLOBAL void gn_finalize_kernel(const GnFinalizeParams p) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= p.nstat * p.C) return;
-  const int stat = i / p.C, c = i - stat * p.C;
-  const int g = c / (p.C >> 5);
-  const double mean = p.sums[(size_t)stat * 64 + 2 * g] / p.count;
-  double var = p.sums[(size_t)stat * 64 + 2 * g + 1] / p.count - mean * mean;
+  const int lane = threadIdx.x & 63;
+  const int wg = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);   // (stat, group) index
+  if (wg >= p.nstat * 32) return;
+  const int stat = wg >> 5, g = wg & 31;
+  double a = 0.0, b = 0.0;
+  for (int sl = lane; sl < p.nslab; sl += 64) {
+    const double* q = p.partial + (((size_t)stat * p.nslab + sl) * 32 + g) * 2;
+    a += q[0];
+    b += q[1];
+  }
+  // fixed-order tree over the 64 lanes (two floats carry one double: hi/lo split keeps it exact enough and deterministic)
+  for (int m = 32; m >= 1; m >>= 1) {
+    const float ah = (float)a, al = (float)(a - (double)ah), bh = (float)b, bl = (float)(b - (double)bh);
+    a += (double)shfl_xor(ah, m) + (double)shfl_xor(al, m);
+    b += (double)shfl_xor(bh, m) + (double)shfl_xor(bl, m);
+  }
+  const double mean = a / p.count;
+  double var = b / p.count - mean * mean;
   if (var < 0) var = 0;
   const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
-  const float a = p.gamma[c] * rstd;
-  p.ab[2 * (size_t)i] = a;
-  p.ab[2 * (size_t)i + 1] = p.beta[c] - (float)mean * a;
+  const int cg = p.C >> 5;
+  for (int c = g * cg + lane; c < (g + 1) * cg; c += 64) {
+    const float sc = p.gamma[c] * rstd;
+    p.ab[2 * ((size_t)stat * p.C + c)] = sc;
+    p.ab[2 * ((size_t)stat * p.C + c) + 1] = p.beta[c] - (float)mean * sc;
+  }
 }
 
 struct GnApplyParams {

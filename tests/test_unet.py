@@ -132,12 +132,10 @@ def test_cfg_pair_is_bit_identical_to_two_forwards(backend, request):
     a = net(x.to(dev), t=t, y=y.to(dev), hint=hint.to(dev))
     b = net(x.to(dev), t=t, y=y2.to(dev), hint=hint.to(dev))
     pa, pb = net.forward_cfg_pair(x.to(dev), t, y.to(dev), y2.to(dev), hint=hint.to(dev))
-    if backend == "emu":
-        assert torch.equal(a, pa) and torch.equal(b, pb)        # same kernels, same order: bit-identical
-    else:
-        # on hardware the GroupNorm statistics are accumulated with fp64 atomics whose order varies from launch to launch,
-        # so even two identical calls can differ in the last bits; the pair must agree to that level
-        assert rel_rms(pa, a) < 2e-3 and rel_rms(pb, b) < 2e-3, (rel_rms(pa, a), rel_rms(pb, b))
+    # every kernel reduces in a fixed order (no atomics anywhere on the path): the forward is bit-reproducible, on the
+    # emulator and on hardware alike, and the shared-prefix pair is bit-identical to two plain calls
+    assert torch.equal(a, pa) and torch.equal(b, pb)
+    assert torch.equal(a, net(x.to(dev), t=t, y=y.to(dev), hint=hint.to(dev)))
     assert rel_rms(pa, pb) > 1e-2
 
 
