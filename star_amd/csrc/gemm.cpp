@@ -4,7 +4,7 @@
 
 namespace star {
 
-template <class T, int BM, int BN, int WM, int WN, int MINW, bool F32OUT>
+template <class T, int BM, int BN, int WM, int WN, int MINW, bool F32OUT, bool STAGGER>
 static int launch_gemm_f(Ctx* ctx, const GemmArgs& a) {
   GemmParams p{};
   p.A = a.A; p.W = a.W; p.C = a.C; p.bias = a.bias; p.res = a.res; p.zero_page = ctx->zero_page;
@@ -16,19 +16,19 @@ static int launch_gemm_f(Ctx* ctx, const GemmArgs& a) {
   const size_t smem = 2 * (size_t)(BM + BN) * 128;
   dim3 grid((unsigned)(p.tiles_m * p.tiles_n)), block(WM * WN * 64);
   switch (a.mode) {
-    case A_PLAIN: STAR_LAUNCH((gemm_kernel<T, BM, BN, WM, WN, A_PLAIN, MINW, F32OUT>), grid, block, smem, ctx->stream, p); break;
-    case A_CONV3X3: STAR_LAUNCH((gemm_kernel<T, BM, BN, WM, WN, A_CONV3X3, MINW, F32OUT>), grid, block, smem, ctx->stream, p); break;
-    case A_CONV3X3_UP: STAR_LAUNCH((gemm_kernel<T, BM, BN, WM, WN, A_CONV3X3_UP, MINW, F32OUT>), grid, block, smem, ctx->stream, p); break;
-    case A_TCONV3: STAR_LAUNCH((gemm_kernel<T, BM, BN, WM, WN, A_TCONV3, MINW, F32OUT>), grid, block, smem, ctx->stream, p); break;
+    case A_PLAIN: STAR_LAUNCH((gemm_kernel<T, BM, BN, WM, WN, A_PLAIN, MINW, F32OUT, STAGGER>), grid, block, smem, ctx->stream, p); break;
+    case A_CONV3X3: STAR_LAUNCH((gemm_kernel<T, BM, BN, WM, WN, A_CONV3X3, MINW, F32OUT, STAGGER>), grid, block, smem, ctx->stream, p); break;
+    case A_CONV3X3_UP: STAR_LAUNCH((gemm_kernel<T, BM, BN, WM, WN, A_CONV3X3_UP, MINW, F32OUT, STAGGER>), grid, block, smem, ctx->stream, p); break;
+    case A_TCONV3: STAR_LAUNCH((gemm_kernel<T, BM, BN, WM, WN, A_TCONV3, MINW, F32OUT, STAGGER>), grid, block, smem, ctx->stream, p); break;
     default: return ctx->fail("gemm: bad A mode");
   }
   return 0;
 }
 
-template <class T, int BM, int BN, int WM, int WN, int MINW>
+template <class T, int BM, int BN, int WM, int WN, int MINW, bool STAGGER = false>
 static int launch_gemm_t(Ctx* ctx, const GemmArgs& a) {
-  if (a.epi & EPI_OUT_F32) return launch_gemm_f<T, BM, BN, WM, WN, MINW, true>(ctx, a);
-  return launch_gemm_f<T, BM, BN, WM, WN, MINW, false>(ctx, a);
+  if (a.epi & EPI_OUT_F32) return launch_gemm_f<T, BM, BN, WM, WN, MINW, true, false>(ctx, a);
+  return launch_gemm_f<T, BM, BN, WM, WN, MINW, false, STAGGER>(ctx, a);
 }
 
 template <class T>
@@ -48,6 +48,8 @@ static int launch_gemm(Ctx* ctx, const GemmArgs& a) {
     case 2: return launch_gemm_t<T, 256, 320, 4, 2, 2>(ctx, a);
     case 3: return launch_gemm_t<T, 128, 128, 2, 2, 2>(ctx, a);
     case 4: return launch_gemm_t<T, 256, 128, 4, 1, 1>(ctx, a);
+    case 5: return launch_gemm_t<T, 256, 256, 4, 2, 2, true>(ctx, a);   // staggered wave groups (A/B)
+    // (the 256x320 tile has no room for the carried fragments: 730+ VGPR spills when staggered)
   }
   return ctx->fail("gemm: bad tile id");
 }

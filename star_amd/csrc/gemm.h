@@ -52,7 +52,7 @@ STAR_DEV float gelu_erf(float x) {
   return 0.5f * x * (1.0f + erf_x);
 }
 
-template <class T, int BM, int BN, int WM, int WN, int AMODE, int MINW, bool F32OUT>
+template <class T, int BM, int BN, int WM, int WN, int AMODE, int MINW, bool F32OUT, bool STAGGER>
 STAR_GLOBAL void STAR_LAUNCH_BOUNDS(WM * WN * 64, MINW)
 gemm_kernel(const GemmParams p) {
   constexpr int NT = WM * WN * 64;
@@ -173,43 +173,52 @@ gemm_kernel(const GemmParams p) {
   // fragment read offsets (bytes within a stage); row R, chunk c -> R*128 + ((c ^ ((R>>1)&7))<<4)
   const int frow = lane & 31, fhalf = lane >> 5;
 
+  // Staggered wave groups.  The two waves that share a SIMD (w and w+4) belong to this same workgroup and meet at the
+  // same barrier every K tile; left alone they run in lockstep -- both issue the next tile's LDS-DMA + address VALU, both
+  // wait on LDS, both then fight for the matrix pipe -- and nothing overlaps.  Waves 4-7 ("late") therefore run one
+  // k-step behind: they carry the fragments of their last k-step across the barrier and issue that MFMA burst first,
+  // beside the early group's load/address/LDS-wait phase; from then on the two groups alternate.
+  const bool late = STAGGER && (wave_uniform(wave) >= NT / 128);
+  vec<T, 8> af_hold[TM], wf_hold[TN];
+  auto mfma_step = [&](const vec<T, 8> (&a)[TM], const vec<T, 8> (&w)[TN]) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = mfma32<T>(w[j], a[i], acc[i][j]);
+  };
   stage(0, 0);
   for (int kt = 0; kt < nk; ++kt) {
     glds_wait();
     block_sync();
     if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+    if (late && kt > 0) mfma_step(af_hold, wf_hold);   // k-step 3 of the previous tile
     const char* abuf = smem + (kt & 1) * STAGE;
     const char* wbuf = abuf + A_STAGE;
-    // fragments of k-step ks+1 are requested BEFORE the MFMAs of k-step ks (explicit register double buffer): the
-    // ~130-cycle LDS latency hides under the MFMA burst instead of being exposed four times per K tile
-    vec<T, 8> af[2][TM], wf[2][TN];
-    auto load_frags = [&](int ks, int slot) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      vec<T, 8> af[TM], wf[TN];
       const int c = ks * 2 + fhalf;
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int R = wm * WTM + i * 32 + frow;
-        af[slot][i] = *reinterpret_cast<const vec<T, 8>*>(abuf + R * 128 + ((c ^ ((R >> 1) & 7)) << 4));
+        af[i] = *reinterpret_cast<const vec<T, 8>*>(abuf + R * 128 + ((c ^ ((R >> 1) & 7)) << 4));
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int R = wn * WTN + j * 32 + frow;
-        wf[slot][j] = *reinterpret_cast<const vec<T, 8>*>(wbuf + R * 128 + ((c ^ ((R >> 1) & 7)) << 4));
+        wf[j] = *reinterpret_cast<const vec<T, 8>*>(wbuf + R * 128 + ((c ^ ((R >> 1) & 7)) << 4));
       }
-    };
-    load_frags(0, 0);
+      if (ks == 3 && late) {
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      if (ks < 3) {
-        load_frags(ks + 1, (ks + 1) & 1);
-        // (pinning these reads above the MFMA burst with sched_barrier(0) was measured: conv 1000 -> 830 TF/s, GEMM neutral
-        //  -- profiles/r01_gemm_prefetch_fence_ab.txt -- so the scheduler is left free)
+        for (int i = 0; i < TM; ++i) af_hold[i] = af[i];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) wf_hold[j] = wf[j];
+      } else {
+        mfma_step(af, wf);
       }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = mfma32<T>(wf[ks & 1][j], af[ks & 1][i], acc[i][j]);
     }
   }
+  if (late) mfma_step(af_hold, wf_hold);
 
   // ------------------------------------------------------------------ epilogue
   // lane holds, for m = i*32 + (lane&31): n = j*32 + 8*(r>>2) + 4*(lane>>5) + (r&3).  N % 8 == 0 (T out) / N % 4 == 0

@@ -47,15 +47,15 @@ int op_group_norm(Ctx* ctx, const void* x, int ldx, void* y, int ldy, const floa
 }
 
 template <class T>
-static int ln_t(Ctx* ctx, const LnParams& p) {
+static int ln_t(Ctx* ctx, LnParams p) {
   const int CC8 = p.C / 8;
-  const int per_lane = (CC8 + 63) / 64;
-  dim3 grid((unsigned)((p.rows + 3) / 4)), block(256);
-  if (per_lane <= 1) STAR_LAUNCH((ln_kernel<T, 1>), grid, block, (size_t)0, ctx->stream, p);
-  else if (per_lane <= 2) STAR_LAUNCH((ln_kernel<T, 2>), grid, block, (size_t)0, ctx->stream, p);
-  else if (per_lane <= 3) STAR_LAUNCH((ln_kernel<T, 3>), grid, block, (size_t)0, ctx->stream, p);
-  else if (per_lane <= 5) STAR_LAUNCH((ln_kernel<T, 5>), grid, block, (size_t)0, ctx->stream, p);
-  else return ctx->fail("layer_norm: C too large (max 2560)");
+  int lpr = 8;
+  while (lpr * 5 < CC8) lpr <<= 1;
+  if (lpr > 64) return ctx->fail("layer_norm: C too large (max 2560)");
+  p.lpr = lpr;
+  const int rows_per_block = 4 * (64 / lpr);
+  dim3 grid((unsigned)((p.rows + rows_per_block - 1) / rows_per_block)), block(256);
+  STAR_LAUNCH((ln_kernel<T>), grid, block, (size_t)0, ctx->stream, p);
   return 0;
 }
 
@@ -65,7 +65,7 @@ int op_layer_norm(Ctx* ctx, const void* x, int ldx, void* y, int ldy, const floa
   if ((ldx | ldy) & 7) return ctx->fail("layer_norm: row strides must be multiples of 8");
   if (rows <= 0) return 0;
   ProfScope ps(ctx, PK_LN, 0.0, (mode == LN_STATS_ONLY ? 1.0 : 2.0) * rows * (double)C * 2.0);
-  LnParams p{x, y, gamma, beta, gate_w, maps, ldx, ldy, C, rows, H, W, eps, mode};
+  LnParams p{x, y, gamma, beta, gate_w, maps, ldx, ldy, C, rows, H, W, eps, mode, 64};
   if (ctx->dtype == DT_F16) return ln_t<f16>(ctx, p);
   return ln_t<bf16>(ctx, p);
 }

@@ -133,20 +133,27 @@ struct LnParams {
   const float* gate_w;   // LINEAR: [2]; MAP: [2][7][7]
   float* maps;           // [tokens][2] (written by STATS_ONLY, read by GATE_MAP)
   int ldx, ldy, C, rows; int H, W;  // H,W: image size for GATE_MAP (token = (f*H + y)*W + x)
-  float eps; int mode;
+  float eps; int mode; int lpr;
 };
-template <class T, int MAXCH>   // MAXCH: 16-B chunks per lane (C <= 512*MAXCH)
+// A row is shared by LPR = 8 / 16 / 32 / 64 lanes (<= 5 16-B chunks per lane), so a wavefront normalises 64/LPR rows at
+// once and every lane is busy at every layer width (C = 320: 8 lanes x 5 chunks, 8 rows per wave; C = 2560: one row).
+template <class T>
 STAR_GLOBAL void ln_kernel(const LnParams p) {
+  constexpr int CPL = 5;
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int LPR = p.lpr;                       // lanes per row (power of two)
+  const int sub = lane & (LPR - 1), rowi = lane / LPR, rpw = 64 / LPR;
+  const int row = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * rpw + rowi;
   const bool active = row < p.rows;
   const int rr = active ? row : p.rows - 1;
   const int CC8 = p.C >> 3;
-  float v[MAXCH][8];
+  auto group_sum = [&](float v) { for (int m = LPR >> 1; m >= 1; m >>= 1) v += shfl_xor(v, m); return v; };
+  auto group_max = [&](float v) { for (int m = LPR >> 1; m >= 1; m >>= 1) v = fmaxf(v, shfl_xor(v, m)); return v; };
+  float v[CPL][8];
   float mx = -3.0e38f, sum = 0.f;
 #pragma unroll
-  for (int i = 0; i < MAXCH; ++i) {
-    const int cc = lane + 64 * i;
+  for (int i = 0; i < CPL; ++i) {
+    const int cc = sub + LPR * i;
     if (cc < CC8) {
       const vec<T, 8> t = *reinterpret_cast<const vec<T, 8>*>((const T*)p.x + (size_t)rr * p.ldx + cc * 8);
 #pragma unroll
@@ -156,12 +163,12 @@ STAR_GLOBAL void ln_kernel(const LnParams p) {
       for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
     }
   }
-  sum = wave_sum(sum);
+  sum = group_sum(sum);
   const float inv_c = 1.0f / (float)p.C;
   float mean = sum * inv_c;
-  if (p.mode != LN_PLAIN) mx = wave_max(mx);
+  if (p.mode != LN_PLAIN) mx = group_max(mx);
   if (p.mode == LN_STATS_ONLY) {
-    if (active && lane == 0) { p.maps[2 * (size_t)row] = mx; p.maps[2 * (size_t)row + 1] = mean; }
+    if (active && sub == 0) { p.maps[2 * (size_t)row] = mx; p.maps[2 * (size_t)row + 1] = mean; }
     return;
   }
   float gate = 1.0f;
@@ -172,37 +179,37 @@ STAR_GLOBAL void ln_kernel(const LnParams p) {
     const int f = rr / hw, rem = rr - f * hw;
     const int y = rem / p.W, x = rem - y * p.W;
     float acc = 0.f;
-    for (int tap = lane; tap < 98; tap += 64) {
+    for (int tap = sub; tap < 98; tap += LPR) {
       const int ch = tap / 49, k = tap - ch * 49;
       const int dy = k / 7 - 3, dx = k - (k / 7) * 7 - 3;
       const int yy = y + dy, xx = x + dx;
       if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W)
         acc += p.gate_w[tap] * p.maps[2 * ((size_t)f * hw + (size_t)yy * p.W + xx) + ch];
     }
-    gate = sigmoid_f(wave_sum(acc));
+    gate = sigmoid_f(group_sum(acc));
   }
   if (p.mode != LN_PLAIN) {
     mean *= gate;
 #pragma unroll
-    for (int i = 0; i < MAXCH; ++i)
+    for (int i = 0; i < CPL; ++i)
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[i][e] *= gate;
   }
   float sq = 0.f;
 #pragma unroll
-  for (int i = 0; i < MAXCH; ++i) {
-    const int cc = lane + 64 * i;
+  for (int i = 0; i < CPL; ++i) {
+    const int cc = sub + LPR * i;
     if (cc < CC8) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; sq += d * d; }
     }
   }
-  sq = wave_sum(sq);
+  sq = group_sum(sq);
   const float rstd = 1.0f / sqrtf(sq * inv_c + p.eps);
   if (!active) return;
 #pragma unroll
-  for (int i = 0; i < MAXCH; ++i) {
-    const int cc = lane + 64 * i;
+  for (int i = 0; i < CPL; ++i) {
+    const int cc = sub + LPR * i;
     if (cc < CC8) {
       const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.gamma + cc * 8), g1 = *reinterpret_cast<const f32x4*>(p.gamma + cc * 8 + 4);
       const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.beta + cc * 8), b1 = *reinterpret_cast<const f32x4*>(p.beta + cc * 8 + 4);

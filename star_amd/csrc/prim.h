@@ -289,6 +289,14 @@ STAR_DEV float dot2_ones(vec<T, 2> a, float acc) {
   }
 #endif
 }
+// tell the compiler a value is wave-uniform (v_readfirstlane); identity on the emulator
+STAR_DEV int wave_uniform(int v) {
+#ifdef STAR_HOSTEMU
+  return v;
+#else
+  return __builtin_amdgcn_readfirstlane(v);
+#endif
+}
 // wave-uniform "any lane has pred"
 STAR_DEV bool wave_any(bool pred) {
 #ifdef STAR_HOSTEMU

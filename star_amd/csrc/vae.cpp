@@ -202,6 +202,7 @@ int vae_encode(Ctx* ctx, const float* x, float* moments, int n, int H, int W) {
   const VaeCfg& cfg = M.cfg;
   const int fdown = 1 << (cfg.n_blocks - 1);
   if (H % fdown || W % fdown) return ctx->fail("vae_encode: H and W must be multiples of the downsampling factor");
+  if (((H / fdown) * (W / fdown)) % 8) return ctx->fail("vae_encode: latent H*W must be a multiple of 8 (legal STAR sizes have W % 64 == 0)");
   const int L2 = 2 * cfg.latent;
   for (int i = 0; i < n; ++i) {   // one frame per pass, as the reference does (video_to_video_model.py:153-161)
     VRun r; r.ctx = ctx; r.F = 1; r.es = ctx->esize();
@@ -236,6 +237,7 @@ int vae_decode(Ctx* ctx, const float* z, float* out, int n, int h, int w) {
   if (!ctx->vae) return ctx->fail("vae_decode: no model built (star_vae_build)");
   const VaeModel& M = *ctx->vae;
   const VaeCfg& cfg = M.cfg;
+  if ((h * w) % 8) return ctx->fail("vae_decode: latent h*w must be a multiple of 8 (legal STAR sizes have w % 8 == 0)");
   VRun r; r.ctx = ctx; r.F = n; r.es = ctx->esize();
   Buf cols(ctx, (size_t)n * h * w * 64 * r.es);
   if (!cols.p) return ctx->fail("out of device memory");
