@@ -37,7 +37,17 @@ STAR_GLOBAL void gn_stats_kernel(const GnStatsParams p) {
   for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; }
   const T* __restrict__ base = (const T*)p.x + ((size_t)stat * p.rows_per_stat) * p.ld + cc * 8;
   if (rl < RL) {
-    for (int r = r0 + rl; r < r1; r += RL) {
+    int r = r0 + rl;
+    for (; r + 3 * RL < r1; r += 4 * RL) {   // four independent 16-B loads in flight per lane
+      vec<T, 8> v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const vec<T, 8>*>(base + (size_t)(r + u * RL) * p.ld);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float f = to_f32<T>(v[u][e]); s[e] += f; ss[e] += f * f; }
+    }
+    for (; r < r1; r += RL) {
       const vec<T, 8> v = *reinterpret_cast<const vec<T, 8>*>(base + (size_t)r * p.ld);
 #pragma unroll
       for (int e = 0; e < 8; ++e) { const float f = to_f32<T>(v[e]); s[e] += f; ss[e] += f * f; }
@@ -105,10 +115,10 @@ template <class T>
 STAR_GLOBAL void gn_apply_kernel(const GnApplyParams p) {
   const int CC8 = p.C >> 3;
   const long long total = (long long)p.rows * CC8;
-  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long long)gridDim.x * blockDim.x) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  auto one = [&](long long q, const vec<T, 8>& v) {
     const int row = (int)(q / CC8), cc = (int)(q - (long long)row * CC8);
     const int stat = row / p.rows_per_stat;
-    const vec<T, 8> v = *reinterpret_cast<const vec<T, 8>*>((const T*)p.x + (size_t)row * p.ldx + cc * 8);
     const float* ab = p.ab + 2 * ((size_t)stat * p.C + cc * 8);
     const f32x4 ab0 = *reinterpret_cast<const f32x4*>(ab), ab1 = *reinterpret_cast<const f32x4*>(ab + 4),
                 ab2 = *reinterpret_cast<const f32x4*>(ab + 8), ab3 = *reinterpret_cast<const f32x4*>(ab + 12);
@@ -122,7 +132,20 @@ STAR_GLOBAL void gn_apply_kernel(const GnApplyParams p) {
       o[e] = from_f32<T>(f);
     }
     *reinterpret_cast<vec<T, 8>*>((T*)p.y + (size_t)row * p.ldy + cc * 8) = o;
+  };
+  auto src = [&](long long q) {
+    const int row = (int)(q / CC8), cc = (int)(q - (long long)row * CC8);
+    return reinterpret_cast<const vec<T, 8>*>((const T*)p.x + (size_t)row * p.ldx + cc * 8);
+  };
+  long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; q + 3 * stride < total; q += 4 * stride) {   // four independent 16-B loads in flight per lane
+    vec<T, 8> v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = *src(q + u * stride);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) one(q + u * stride, v[u]);
   }
+  for (; q < total; q += stride) one(q, *src(q));
 }
 
 // ------------------------------------------------------------------ LayerNorm rows (+ LIEM gates)
