@@ -4,7 +4,7 @@
 
 namespace star {
 
-template <class T, int BM, int BN, int WM, int WN, int MINW, bool F32OUT, bool STAGGER>
+template <class T, int BM, int BN, int WM, int WN, int MINW, bool F32OUT, bool STAGGER, int PIPE = 0>
 static int launch_gemm_f(Ctx* ctx, const GemmArgs& a) {
   GemmParams p{};
   p.A = a.A; p.W = a.W; p.C = a.C; p.bias = a.bias; p.res = a.res; p.zero_page = ctx->zero_page;
@@ -13,22 +13,25 @@ static int launch_gemm_f(Ctx* ctx, const GemmArgs& a) {
   p.HW = a.HW; p.F = a.F; p.up_crop = a.up_crop; p.epi = a.epi;
   p.tiles_m = (a.M + BM - 1) / BM;
   p.tiles_n = (a.N + BN - 1) / BN;
-  const size_t smem = 2 * (size_t)(BM + BN) * 128;
+  // 2 stages x 64 k, or PIPE ring slots x 32 k; never less than the epilogue's per-wave staging blocks
+  constexpr size_t smem_loop = PIPE ? (size_t)PIPE * (BM + BN) * 64 : 2 * (size_t)(BM + BN) * 128;
+  constexpr size_t smem_epi = (size_t)WM * WN * 32 * (BN / WN * 2 + 8);
+  constexpr size_t smem = smem_loop > smem_epi ? smem_loop : smem_epi;
   dim3 grid((unsigned)(p.tiles_m * p.tiles_n)), block(WM * WN * 64);
   switch (a.mode) {
-    case A_PLAIN: STAR_LAUNCH((gemm_kernel<T, BM, BN, WM, WN, A_PLAIN, MINW, F32OUT, STAGGER>), grid, block, smem, ctx->stream, p); break;
-    case A_CONV3X3: STAR_LAUNCH((gemm_kernel<T, BM, BN, WM, WN, A_CONV3X3, MINW, F32OUT, STAGGER>), grid, block, smem, ctx->stream, p); break;
-    case A_CONV3X3_UP: STAR_LAUNCH((gemm_kernel<T, BM, BN, WM, WN, A_CONV3X3_UP, MINW, F32OUT, STAGGER>), grid, block, smem, ctx->stream, p); break;
-    case A_TCONV3: STAR_LAUNCH((gemm_kernel<T, BM, BN, WM, WN, A_TCONV3, MINW, F32OUT, STAGGER>), grid, block, smem, ctx->stream, p); break;
+    case A_PLAIN: STAR_LAUNCH((gemm_kernel<T, BM, BN, WM, WN, A_PLAIN, MINW, F32OUT, STAGGER, 0, PIPE>), grid, block, smem, ctx->stream, p); break;
+    case A_CONV3X3: STAR_LAUNCH((gemm_kernel<T, BM, BN, WM, WN, A_CONV3X3, MINW, F32OUT, STAGGER, 0, PIPE>), grid, block, smem, ctx->stream, p); break;
+    case A_CONV3X3_UP: STAR_LAUNCH((gemm_kernel<T, BM, BN, WM, WN, A_CONV3X3_UP, MINW, F32OUT, STAGGER, 0, PIPE>), grid, block, smem, ctx->stream, p); break;
+    case A_TCONV3: STAR_LAUNCH((gemm_kernel<T, BM, BN, WM, WN, A_TCONV3, MINW, F32OUT, STAGGER, 0, PIPE>), grid, block, smem, ctx->stream, p); break;
     default: return ctx->fail("gemm: bad A mode");
   }
   return 0;
 }
 
-template <class T, int BM, int BN, int WM, int WN, int MINW, bool STAGGER = false>
+template <class T, int BM, int BN, int WM, int WN, int MINW, bool STAGGER = false, int PIPE = 0>
 static int launch_gemm_t(Ctx* ctx, const GemmArgs& a) {
-  if (a.epi & EPI_OUT_F32) return launch_gemm_f<T, BM, BN, WM, WN, MINW, true, false>(ctx, a);
-  return launch_gemm_f<T, BM, BN, WM, WN, MINW, false, STAGGER>(ctx, a);
+  if (a.epi & EPI_OUT_F32) return launch_gemm_f<T, BM, BN, WM, WN, MINW, true, false, 0>(ctx, a);
+  return launch_gemm_f<T, BM, BN, WM, WN, MINW, false, STAGGER, PIPE>(ctx, a);
 }
 
 template <class T>
@@ -50,6 +53,24 @@ static int launch_gemm(Ctx* ctx, const GemmArgs& a) {
     case 4: return launch_gemm_t<T, 256, 128, 4, 1, 1>(ctx, a);
     case 5: return launch_gemm_t<T, 256, 256, 4, 2, 2, true>(ctx, a);   // staggered wave groups (A/B)
     // (the 256x320 tile has no room for the carried fragments: 730+ VGPR spills when staggered)
+    case 7: return launch_gemm_t<T, 256, 256, 4, 2, 2, false, 4>(ctx, a);   // pipelined main loop (ring of 4 x 32-k slots)
+    case 8: return launch_gemm_t<T, 256, 320, 4, 2, 2, false, 4>(ctx, a);
+    // two independent 4-wave workgroups per CU (72 / 56 KB of LDS each): one group's epilogue and DMA latency hide
+    // behind the other group's MFMA burst
+    case 9: return launch_gemm_t<T, 128, 256, 2, 2, 2, false, 3>(ctx, a);
+    case 10: return launch_gemm_t<T, 128, 320, 2, 2, 2, false, 2>(ctx, a);
+  }
+  if (tile >= 11 && tile <= 13 && a.mode == A_PLAIN && !(a.epi & EPI_OUT_F32)) {   // ablation probes of the 256x256 main loop
+    GemmParams p{};
+    p.A = a.A; p.W = a.W; p.C = a.C; p.bias = a.bias; p.res = a.res; p.zero_page = ctx->zero_page;
+    p.M = a.M; p.N = a.N; p.K = a.K; p.lda = a.lda; p.ldc = a.ldc; p.ldr = a.ldr; p.epi = a.epi;
+    p.tiles_m = (a.M + 255) / 256; p.tiles_n = (a.N + 255) / 256;
+    dim3 grid((unsigned)(p.tiles_m * p.tiles_n)), block(512);
+    const size_t smem = 2 * (size_t)512 * 128;
+    if (tile == 11) STAR_LAUNCH((gemm_kernel<T, 256, 256, 4, 2, A_PLAIN, 2, false, false, 1>), grid, block, smem, ctx->stream, p);
+    if (tile == 12) STAR_LAUNCH((gemm_kernel<T, 256, 256, 4, 2, A_PLAIN, 2, false, false, 2>), grid, block, smem, ctx->stream, p);
+    if (tile == 13) STAR_LAUNCH((gemm_kernel<T, 256, 256, 4, 2, A_PLAIN, 2, false, false, 3>), grid, block, smem, ctx->stream, p);
+    return 0;
   }
   return ctx->fail("gemm: bad tile id");
 }

@@ -52,7 +52,7 @@ STAR_DEV float gelu_erf(float x) {
   return 0.5f * x * (1.0f + erf_x);
 }
 
-template <class T, int BM, int BN, int WM, int WN, int AMODE, int MINW, bool F32OUT, bool STAGGER>
+template <class T, int BM, int BN, int WM, int WN, int AMODE, int MINW, bool F32OUT, bool STAGGER, int ABL = 0, int PIPE = 0>  // ABL: ablation probes (bench only); PIPE: ring slots of the pipelined loop (0 = 2-stage loop)
 STAR_GLOBAL void STAR_LAUNCH_BOUNDS(WM * WN * 64, MINW)
 gemm_kernel(const GemmParams p) {
   constexpr int NT = WM * WN * 64;
@@ -173,6 +173,135 @@ gemm_kernel(const GemmParams p) {
   // fragment read offsets (bytes within a stage); row R, chunk c -> R*128 + ((c ^ ((R>>1)&7))<<4)
   const int frow = lane & 31, fhalf = lane >> 5;
 
+  if constexpr (PIPE != 0) {
+    // ---- pipelined main loop: 32-deep K steps through a ring of PIPE LDS slots, PIPE-1 steps of LDS-DMA in flight across
+    // raw barriers (counted vmcnt, never 0 in steady state for PIPE > 2).  Ablation of the 2-stage loop at 8192^3 (profiles/
+    // r01_gemm_ablation.txt): LDS-DMA + barrier alone 0.90 ms, MFMA + LDS reads alone 0.81 ms, together 1.10 ms -- with only
+    // one 64-deep tile of DMA in flight its latency is exposed every tile.
+    constexpr int SLOT = (BM + BN) * 64;            // bytes: [BM rows | BN rows] x 32 k
+    constexpr int NIA = BM / 16, NIW = BN / 16;      // wave-instructions (64 chunks of 16 B) per step for A / W
+    static_assert(NIA % (NT / 64) == 0, "A part must split evenly over the waves");
+    constexpr int NWV = NT / 64;
+    constexpr int LA = NIA / NWV;                    // A loads per wave per step
+    constexpr int LW0 = NIW / NWV, WX = NIW % NWV;   // W loads per wave per step: LW0 (+1 for waves < WX)
+    const int wv = wave_uniform(wave);
+    const bool wextra = wv < WX;
+    // per-wave loader rows: instruction j covers chunks [64 j, 64 j + 64): row = (64 j + lane) >> 2, pos = lane & 3
+    const int lpos = lane & 3;
+    const T* pa_ptr[LA]; int pa_y[LA], pa_x[LA], pa_f[LA];
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+      const int r = (64 * (wv + NWV * i) + lane) >> 2;
+      const int c = lpos ^ ((r >> 2) & 3);
+      int m = m0 + r;
+      if (m > p.M - 1) m = p.M - 1;
+      if constexpr (AMODE == A_PLAIN) { pa_ptr[i] = Ag + (size_t)m * p.lda + c * 8; pa_y[i] = pa_x[i] = pa_f[i] = 0; }
+      else if constexpr (AMODE == A_TCONV3) { pa_ptr[i] = Ag + (size_t)m * p.lda + c * 8; pa_f[i] = m / p.HW; pa_y[i] = pa_x[i] = 0; }
+      else {
+        const int hw = p.Ho * p.Wo;
+        const int nb = m / hw, rem = m - nb * hw;
+        const int yo = rem / p.Wo, xo = rem - yo * p.Wo;
+        pa_ptr[i] = Ag + (size_t)nb * p.H * p.Wd * p.lda + c * 8;
+        pa_y[i] = yo * p.stride - p.pad_t; pa_x[i] = xo * p.stride - p.pad_l; pa_f[i] = 0;
+      }
+    }
+    const T* pw_ptr[LW0 + 1];
+#pragma unroll
+    for (int i = 0; i < LW0 + 1; ++i) {
+      const int r = (64 * (wv + NWV * i) + lane) >> 2;
+      const int c = lpos ^ ((r >> 2) & 3);
+      int n = n0 + r;
+      if (n > p.N - 1) n = p.N - 1;
+      pw_ptr[i] = Wg + (size_t)n * p.K + c * 8;
+    }
+    const int nsteps = p.K / 32;
+    int ptap = 0, pc0 = 0;
+    constexpr int INF = PIPE - 2;                    // steps that may stay in flight while step st+1 is awaited
+    auto issue = [&](int s_, int slot) {   // LDS-DMA of K step s_ into ring slot `slot` (= s_ % PIPE)
+      char* abuf = smem + slot * SLOT;
+      char* wbuf = abuf + BM * 64;
+      int ky = 0, kx = 0;
+      if constexpr (AMODE == A_CONV3X3 || AMODE == A_CONV3X3_UP) { ky = ptap / 3; kx = ptap - ky * 3; }
+#pragma unroll
+      for (int i = 0; i < LA; ++i) {
+        const void* src;
+        if constexpr (AMODE == A_PLAIN) src = pa_ptr[i] + s_ * 32;
+        else if constexpr (AMODE == A_TCONV3) {
+          const int f = pa_f[i] + ptap - 1;
+          src = (f >= 0 && f < p.F) ? (const void*)(pa_ptr[i] + (ptrdiff_t)(ptap - 1) * p.HW * p.lda + pc0) : p.zero_page;
+        } else if constexpr (AMODE == A_CONV3X3) {
+          const int yi = pa_y[i] + ky, xi = pa_x[i] + kx;
+          src = (yi >= 0 && yi < p.H && xi >= 0 && xi < p.Wd) ? (const void*)(pa_ptr[i] + ((size_t)yi * p.Wd + xi) * p.lda + pc0) : p.zero_page;
+        } else {
+          const int yu = pa_y[i] + ky, xu = pa_x[i] + kx;
+          src = (yu >= 0 && yu < 2 * p.H - 2 * p.up_crop && xu >= 0 && xu < 2 * p.Wd)
+                    ? (const void*)(pa_ptr[i] + ((size_t)((yu + p.up_crop) >> 1) * p.Wd + (xu >> 1)) * p.lda + pc0) : p.zero_page;
+        }
+        glds16(src, abuf + (size_t)(wv + NWV * i) * 1024);
+      }
+#pragma unroll
+      for (int i = 0; i < LW0; ++i) glds16(pw_ptr[i] + s_ * 32, wbuf + (size_t)(wv + NWV * i) * 1024);
+      if (WX > 0 && wextra) glds16(pw_ptr[LW0] + s_ * 32, wbuf + (size_t)(wv + NWV * LW0) * 1024);
+      if constexpr (AMODE != A_PLAIN) { pc0 += 32; if (pc0 >= p.Cin) { pc0 = 0; ++ptap; } }
+    };
+    // wait until at most `steps_in_flight` K steps of this wave's DMA are outstanding
+    auto wait_steps = [&](int steps_in_flight) {
+      if constexpr (INF >= 2) {
+        if (steps_in_flight >= 2) {
+          if (WX > 0 && wextra) { STAR_WAIT_VMCNT_N(2 * (LA + LW0 + 1)); } else { STAR_WAIT_VMCNT_N(2 * (LA + LW0)); }
+          return;
+        }
+      }
+      if constexpr (INF >= 1) {
+        if (steps_in_flight >= 1) {
+          if (WX > 0 && wextra) { STAR_WAIT_VMCNT_N(LA + LW0 + 1); } else { STAR_WAIT_VMCNT_N(LA + LW0); }
+          return;
+        }
+      }
+      STAR_WAIT_VMCNT_N(0);
+    };
+    // prologue: PIPE-1 steps in flight, step 0 landed
+    issue(0, 0);
+#pragma unroll
+    for (int q = 1; q < PIPE - 1; ++q)
+      if (nsteps > q) issue(q, q);
+    {
+      const int ahead = (nsteps - 1 < PIPE - 2) ? nsteps - 1 : PIPE - 2;   // issued steps beyond step 0
+      wait_steps(ahead);
+    }
+    barrier_keep_dma();
+    int rslot = 0, islot = PIPE - 1;                    // ring slot being read / to be filled next
+    for (int st = 0; st < nsteps; ++st) {
+      if (st + PIPE - 1 < nsteps) issue(st + PIPE - 1, islot);   // that slot was read in step st-1: every wave is past its barrier
+      const char* abuf = smem + rslot * SLOT;
+      const char* wbuf = abuf + BM * 64;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        vec<T, 8> af[TM], wf[TN];
+        const int c = u * 2 + fhalf;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int R = wm * WTM + i * 32 + frow;
+          af[i] = *reinterpret_cast<const vec<T, 8>*>(abuf + R * 64 + ((c ^ ((R >> 2) & 3)) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int R = wn * WTN + j * 32 + frow;
+          wf[j] = *reinterpret_cast<const vec<T, 8>*>(wbuf + R * 64 + ((c ^ ((R >> 2) & 3)) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = mfma32<T>(wf[j], af[i], acc[i][j]);
+      }
+      // step st+1 must have landed before anyone reads it: after this wait at most the DMA of steps st+2.. is pending
+      const int remaining = nsteps - 1 - st;         // steps after this one
+      wait_steps(remaining - 1 < INF ? remaining - 1 : INF);
+      barrier_keep_dma();
+      rslot = (rslot + 1 == PIPE) ? 0 : rslot + 1;
+      islot = (islot + 1 == PIPE) ? 0 : islot + 1;
+    }
+  } else {
   // Staggered wave groups.  The two waves that share a SIMD (w and w+4) belong to this same workgroup and meet at the
   // same barrier every K tile; left alone they run in lockstep -- both issue the next tile's LDS-DMA + address VALU, both
   // wait on LDS, both then fight for the matrix pipe -- and nothing overlaps.  Waves 4-7 ("late") therefore run one
@@ -190,7 +319,7 @@ gemm_kernel(const GemmParams p) {
   for (int kt = 0; kt < nk; ++kt) {
     glds_wait();
     block_sync();
-    if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+    if (kt + 1 < nk && (ABL != 3 || kt == 0)) stage(kt + 1, (kt + 1) & 1);
     if (late && kt > 0) mfma_step(af_hold, wf_hold);   // k-step 3 of the previous tile
     const char* abuf = smem + (kt & 1) * STAGE;
     const char* wbuf = abuf + A_STAGE;
@@ -201,12 +330,21 @@ gemm_kernel(const GemmParams p) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int R = wm * WTM + i * 32 + frow;
-        af[i] = *reinterpret_cast<const vec<T, 8>*>(abuf + R * 128 + ((c ^ ((R >> 1) & 7)) << 4));
+        if constexpr (ABL == 1) { for (int e = 0; e < 8; ++e) af[i][e] = from_f32<T>(0.001f * (float)(lane + i + ks)); }
+        else af[i] = *reinterpret_cast<const vec<T, 8>*>(abuf + R * 128 + ((c ^ ((R >> 1) & 7)) << 4));
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int R = wn * WTN + j * 32 + frow;
-        wf[j] = *reinterpret_cast<const vec<T, 8>*>(wbuf + R * 128 + ((c ^ ((R >> 1) & 7)) << 4));
+        if constexpr (ABL == 1) { for (int e = 0; e < 8; ++e) wf[j][e] = from_f32<T>(0.002f * (float)(lane + j + kt)); }
+        else wf[j] = *reinterpret_cast<const vec<T, 8>*>(wbuf + R * 128 + ((c ^ ((R >> 1) & 7)) << 4));
+      }
+      if constexpr (ABL == 2) {   // keep the reads alive without MFMAs
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[i][0][0] += to_f32<T>(af[i][0]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[0][j][1] += to_f32<T>(wf[j][0]);
+        continue;
       }
       if (ks == 3 && late) {
 #pragma unroll
@@ -219,6 +357,8 @@ gemm_kernel(const GemmParams p) {
     }
   }
   if (late) mfma_step(af_hold, wf_hold);
+
+  }
 
   // ------------------------------------------------------------------ epilogue
   // lane holds, for m = i*32 + (lane&31): n = j*32 + 8*(r>>2) + 4*(lane>>5) + (r&3).  N % 8 == 0 (T out) / N % 4 == 0

@@ -177,6 +177,40 @@ STAR_DEV void glds_wait() {
 #endif
 }
 
+// counted wait on the vector-memory queue (LDS-DMA included): at most N of this wave's loads may still be in flight
+#ifdef STAR_HOSTEMU
+#define STAR_WAIT_VMCNT(N)
+#else
+#define STAR_WAIT_VMCNT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+#endif
+// same with a compile-time-computed count (inline asm needs a literal)
+#ifdef STAR_HOSTEMU
+#define STAR_WAIT_VMCNT_N(expr)
+#else
+#define STAR_WAIT_VMCNT_N(expr)                                                            \
+  do {                                                                                     \
+    constexpr int star_n_ = (expr);                                                        \
+    static_assert(star_n_ >= 0 && star_n_ <= 12, "vmcnt count out of the supported range"); \
+    if constexpr (star_n_ == 0) STAR_WAIT_VMCNT(0); else if constexpr (star_n_ == 1) STAR_WAIT_VMCNT(1);      \
+    else if constexpr (star_n_ == 2) STAR_WAIT_VMCNT(2); else if constexpr (star_n_ == 3) STAR_WAIT_VMCNT(3); \
+    else if constexpr (star_n_ == 4) STAR_WAIT_VMCNT(4); else if constexpr (star_n_ == 5) STAR_WAIT_VMCNT(5); \
+    else if constexpr (star_n_ == 6) STAR_WAIT_VMCNT(6); else if constexpr (star_n_ == 7) STAR_WAIT_VMCNT(7); \
+    else if constexpr (star_n_ == 8) STAR_WAIT_VMCNT(8); else if constexpr (star_n_ == 9) STAR_WAIT_VMCNT(9); \
+    else if constexpr (star_n_ == 10) STAR_WAIT_VMCNT(10); else if constexpr (star_n_ == 11) STAR_WAIT_VMCNT(11); \
+    else STAR_WAIT_VMCNT(12);                                                              \
+  } while (0)
+#endif
+// workgroup barrier WITHOUT the vmcnt(0) drain that __syncthreads() implies while LDS-DMA is in flight: own LDS
+// accesses are retired (lgkmcnt(0)), DMA stays in flight across the barrier
+STAR_DEV void barrier_keep_dma() {
+#ifdef STAR_HOSTEMU
+  ::star_emu::block_sync();
+#else
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+#endif
+}
+
 // ---------------------------------------------------------------- transpose read
 // ds_read_b64_tr_b16: every lane passes the (8-byte aligned) LDS address of 4
 // contiguous 16-bit elements P[lane][0..3]; within each 16-lane group lane i
