@@ -138,6 +138,26 @@ int star_vae_encode(star_ctx* ctx, const float* x, float* moments, int32_t n, in
 int star_vae_decode(star_ctx* ctx, const float* z, float* out, int32_t n, int32_t h, int32_t w);
 int star_softmax_rows(star_ctx* ctx, const float* s, int32_t lds, void* p, int32_t ldp, int32_t rows, int32_t n, float scale);
 
+/* ---- full-resolution frame kernels either side of the diffusion path ---------- */
+/* replaces: F.interpolate(video_data, [target_h, target_w], mode='bilinear') + F.pad(video_data, padding, 'constant', 1)
+ * in VideoToVideo_sr.test (video_to_video_model.py:81-87).  src: fp32 device planes x [h][w] (planes = F*3);
+ * dst: fp32 device planes x [th + pad_t + pad_b][tw + pad_l + pad_r]. */
+int star_resize_pad(star_ctx* ctx, const float* src, float* dst, int32_t planes, int32_t h, int32_t w, int32_t th, int32_t tw,
+                    int32_t pad_l, int32_t pad_r, int32_t pad_t, int32_t pad_b, float pad_value);
+/* replaces: calc_mean_std (color_fix.py:62-74) on v = x*scale + shift (clamped to [0,1] when clamp01): per contiguous
+ * plane of n fp32 values -> stats[plane] = (mean, sqrt(unbiased var + eps)) fp32 pairs.  Reproducible (no atomics). */
+int star_plane_stats(star_ctx* ctx, const float* x, float* stats, int32_t planes, int64_t n, float scale, float shift,
+                     int32_t clamp01, float eps);
+/* replaces: tensor2vid (inference_utils.py:16-23) followed by adain_color_fix (color_fix.py:15-29,76-89) as called from
+ * inference_sr.py:47-48.  x: fp32 device [1, C, F, H, W] in ~[-1, 1] (the pipeline output); src: fp32 device
+ * [F, C, h, w] low-resolution clip in [-1, 1]; out: fp32 device [F, H, W, C] in [0, 255]. */
+int star_color_fix(star_ctx* ctx, const float* x, const float* src, float* out, int32_t F, int32_t C, int32_t H, int32_t W,
+                   int32_t h, int32_t w);
+/* replaces: adain_color_fix(target, source) on its own (color_fix.py:15-29): target fp32 device [F, H, W, C] in [0, 255]
+ * (a tensor2vid result), src as above -> out fp32 device [F, H, W, C] in [0, 255]. */
+int star_adain_color_fix(star_ctx* ctx, const float* target, const float* src, float* out, int32_t F, int32_t C, int32_t H,
+                         int32_t W, int32_t h, int32_t w);
+
 /* ---- live per-kernel-family timing (HIP events on the launch stream; used by bench.py's roofline leg) --------- */
 enum { STAR_PK_ATTN_SELF = 0, STAR_PK_ATTN_CROSS, STAR_PK_TATTN, STAR_PK_GEMM, STAR_PK_CONV, STAR_PK_TCONV, STAR_PK_GN,
        STAR_PK_LN, STAR_PK_MISC, STAR_PK_COUNT };

@@ -9,7 +9,9 @@ import torch
 
 
 def tensor2vid(video, mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5)):
-    """[1, 3, F, H, W] in ~[-1, 1] -> [F, H, W, 3] in 0..255 (inference_utils.py:16-23)."""
+    """[1, 3, F, H, W] in ~[-1, 1] -> [F, H, W, 3] in 0..255 (inference_utils.py:16-23): a layout change and an affine
+    map, left to torch on whatever device holds the tensor.  The inference script does not call it: it uses the fused
+    star_amd.frames.tensor2vid_color_fix (one HIP pass for tensor2vid + adain_color_fix) instead."""
     m = torch.tensor(mean, device=video.device).reshape(1, -1, 1, 1, 1)
     s = torch.tensor(std, device=video.device).reshape(1, -1, 1, 1, 1)
     video = (video * s + m).clamp_(0, 1) * 255.0
@@ -47,7 +49,7 @@ def load_video(vid_path):
 
 
 def save_video(video, save_dir, file_name, fps=16.0):
-    """[F, H, W, 3] uint8 -> mp4 through ffmpeg (libx264, crf 0) when available, else a .npy next to it."""
+    """[F, H, W, 3] in 0..255 (float or uint8; truncated like the reference's astype('uint8')) -> mp4 through ffmpeg (libx264, crf 0) when available, else a .npy next to it."""
     os.makedirs(save_dir, exist_ok=True)
     out_path = os.path.join(save_dir, file_name)
     arr = video.cpu().numpy() if torch.is_tensor(video) else np.asarray(video)

@@ -193,6 +193,36 @@ def gen_blocks():
     torch.save(out, os.path.join(GOLD, "blocks.pt"))
 
 
+FRAME_CASES = [  # F, h, w, upscale, seed, resize target (th, tw), padding (l, r, t, b); third: non-integer ratio, no pad
+    (3, 12, 20, 4, 301, (48, 80), (3, 5, 2, 1)), (2, 17, 23, 4, 302, (68, 92), (0, 4, 6, 6)),
+    (1, 9, 13, 2, 303, (25, 30), (0, 0, 0, 0)), (2, 20, 36, 4, 304, (80, 144), (8, 8, 4, 4)),
+]
+
+
+def gen_frames():
+    """tensor2vid + adain_color_fix of the REFERENCE (inference_utils.py:16-23, color_fix.py:15-29) and the two torch
+    calls video_to_video_model.py:81,87 makes for resize + pad (small explicit paddings instead of pad_to_fit's
+    720x1280 minimum, which is pinned separately in sampler.pt); inputs are re-derived from seeds (oracle/frames_oracle.py)."""
+    import torch.nn.functional as F
+    import frames_oracle as fo
+    iu, cf = ref_loader.load_frame_modules()
+    dm = ref_loader.load_diffusion_modules()  # noqa: F841  (logger stand-in)
+    out = {}
+    for (F_, h, w, up, seed, (th, tw), padding) in FRAME_CASES:
+        lr, video = fo.frames_inputs(F_, h, w, up, seed)
+        vid = iu.tensor2vid(video.clone())
+        fixed = cf.adain_color_fix(vid, lr)
+        cm, cs = cf.calc_mean_std(vid.permute(0, 3, 1, 2) / 255)
+        sm, ss = cf.calc_mean_std((lr + 1) / 2)
+        rp = F.pad(F.interpolate(lr, [th, tw], mode="bilinear"), padding, "constant", 1)
+        out[f"f{F_}_{h}x{w}_x{up}"] = {"case": (F_, h, w, up, seed, (th, tw), padding), "color_fix": fixed.clone(),
+                                        "content_stats": torch.stack([cm.flatten(1), cs.flatten(1)], -1),
+                                        "style_stats": torch.stack([sm.flatten(1), ss.flatten(1)], -1),
+                                        "padding": tuple(padding), "resize_pad": rp.clone()}
+        print("frames", F_, h, w, tuple(fixed.shape), tuple(rp.shape), padding)
+    torch.save(out, os.path.join(GOLD, "frames.pt"))
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
@@ -208,6 +238,8 @@ if __name__ == "__main__":
         gen_sampler()
     if only is None or "blocks" in only:
         gen_blocks()
+    if only is None or "frames" in only:
+        gen_frames()
     if only is None or "small" in only:
         gen_unet(SMALL_TEST_CONFIG, SMALL_CASES, "small")
     if a.full:

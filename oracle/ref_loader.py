@@ -132,6 +132,29 @@ def load_diffusion_modules():
     return _cache["diff"]
 
 
+def load_frame_modules():
+    """-> (inference_utils, color_fix) reference modules.  Both import torchvision / cv2 at module level but the
+    functions on this path (tensor2vid; adain_color_fix, calc_mean_std, adaptive_instance_normalization) use torch
+    and einops only, so empty stand-ins are enough."""
+    if "frames" not in _cache:
+        load_diffusion_modules()   # installs the video_to_video.utils.logger stand-in
+        for name in ("cv2", "torchvision", "torchvision.transforms", "torchvision.transforms.functional"):
+            if name not in sys.modules:
+                m = types.ModuleType(name)
+                m.__path__ = []
+                sys.modules[name] = m
+        tvt = sys.modules["torchvision.transforms"]
+        for attr in ("ToTensor", "ToPILImage"):
+            if not hasattr(tvt, attr):
+                setattr(tvt, attr, object)
+        sys.modules["torchvision"].transforms = tvt
+        tvt.functional = sys.modules["torchvision.transforms.functional"]
+        iu = _load_by_path("_star_ref_inference_utils", "inference_utils.py")
+        cf = _load_by_path("_star_ref_color_fix", "video_super_resolution/color_fix.py")
+        _cache["frames"] = (iu, cf)
+    return _cache["frames"]
+
+
 def randomize_zero_init(model, seed=0, std=0.02):
     """Re-draw every all-zero parameter N(0, std^2) so parity is non-vacuous
     (the reference zero-initialises proj_out / zero_convs / out_layers[-1] /

@@ -192,6 +192,31 @@ int star_softmax_rows(star_ctx* h, const float* s, int32_t lds, void* p, int32_t
 }
 
 
+int star_resize_pad(star_ctx* h, const float* src, float* dst, int32_t planes, int32_t hh, int32_t w, int32_t th, int32_t tw,
+                    int32_t pad_l, int32_t pad_r, int32_t pad_t, int32_t pad_b, float pad_value) {
+  if (!h) return -1;
+  rt::set_device(h->c.device);
+  return op_resize_pad(&h->c, src, dst, planes, hh, w, th, tw, pad_l, pad_r, pad_t, pad_b, pad_value);
+}
+int star_plane_stats(star_ctx* h, const float* x, float* stats, int32_t planes, int64_t n, float scale, float shift,
+                     int32_t clamp01, float eps) {
+  if (!h) return -1;
+  rt::set_device(h->c.device);
+  return op_plane_stats(&h->c, x, stats, planes, (long long)n, scale, shift, clamp01 != 0, eps);
+}
+int star_color_fix(star_ctx* h, const float* x, const float* src, float* out, int32_t F, int32_t C, int32_t H, int32_t W,
+                   int32_t hh, int32_t w) {
+  if (!h) return -1;
+  rt::set_device(h->c.device);
+  return op_color_fix(&h->c, x, true, src, out, F, C, H, W, hh, w);
+}
+int star_adain_color_fix(star_ctx* h, const float* target, const float* src, float* out, int32_t F, int32_t C, int32_t H, int32_t W,
+                         int32_t hh, int32_t w) {
+  if (!h) return -1;
+  rt::set_device(h->c.device);
+  return op_color_fix(&h->c, target, false, src, out, F, C, H, W, hh, w);
+}
+
 int star_profile_begin(star_ctx* h) {
   for (auto& r : h->c.prof) { rt::event_destroy(r.e0); rt::event_destroy(r.e1); }
   h->c.prof.clear();

@@ -112,6 +112,10 @@ class Library:
         self.rows_to_latent = _sig(c, "star_rows_to_latent", i32, vp, vp, vp, i32, i32, i64)
         self.gemv = _sig(c, "star_gemv", i32, vp, vp, vp, vp, vp, i32, i32, i32, i32)
         self.cast = _sig(c, "star_cast", i32, vp, vp, vp, i64)
+        self.resize_pad = _sig(c, "star_resize_pad", i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32)
+        self.plane_stats = _sig(c, "star_plane_stats", i32, vp, vp, vp, i32, i64, f32, f32, i32, f32)
+        self.color_fix = _sig(c, "star_color_fix", i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32)
+        self.adain_color_fix = _sig(c, "star_adain_color_fix", i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32)
         self.profile_begin = _sig(c, "star_profile_begin", i32, vp)
         self.profile_end = _sig(c, "star_profile_end", i32, vp, ctypes.POINTER(ProfEntry))
 
@@ -325,6 +329,59 @@ class Context:
         y = torch.empty(N, dtype=torch.float32, device=self.torch_device)
         self._check(self.lib.gemv(self.h, _ptr(x), _ptr(W), _ptr(b), _ptr(y), N, K, int(silu_in), int(silu_out)), "gemv")
         return y
+
+    def resize_pad(self, video, target_hw, padding=(0, 0, 0, 0), pad_value=1.0):
+        """F.interpolate(video, target_hw, mode='bilinear') + F.pad(video, padding, 'constant', pad_value)
+        (video_to_video_model.py:81-87).  video: fp32 [F, C, h, w]; padding = (left, right, top, bottom)."""
+        self._chk_tensor(video, torch.float32)
+        video = video.contiguous()
+        F_, C, h, w = video.shape
+        th, tw = int(target_hw[0]), int(target_hw[1])
+        pl, pr, pt, pb = (int(v) for v in padding)
+        out = torch.empty(F_, C, th + pt + pb, tw + pl + pr, dtype=torch.float32, device=self.torch_device)
+        self._check(self.lib.resize_pad(self.h, _ptr(video), _ptr(out), F_ * C, h, w, th, tw, pl, pr, pt, pb, float(pad_value)),
+                    "resize_pad")
+        return out
+
+    def plane_stats(self, x, scale=1.0, shift=0.0, clamp01=False, eps=1e-5):
+        """calc_mean_std (color_fix.py:62-74) of x*scale+shift over the last two dims -> [..., 2] = (mean, std)."""
+        self._chk_tensor(x, torch.float32)
+        x = x.contiguous()
+        lead = x.shape[:-2]
+        planes = 1
+        for d in lead:
+            planes *= int(d)
+        n = int(x.shape[-2]) * int(x.shape[-1])
+        out = torch.empty(*lead, 2, dtype=torch.float32, device=self.torch_device)
+        self._check(self.lib.plane_stats(self.h, _ptr(x), _ptr(out), planes, n, float(scale), float(shift), int(clamp01), float(eps)),
+                    "plane_stats")
+        return out
+
+    def color_fix(self, video, source):
+        """tensor2vid + adain_color_fix (inference_utils.py:16-23, color_fix.py:15-29).  video: fp32 [1, C, F, H, W];
+        source: fp32 [F, C, h, w] in [-1, 1]  ->  fp32 [F, H, W, C] in [0, 255]."""
+        self._chk_tensor(video, torch.float32); self._chk_tensor(source, torch.float32)
+        video, source = video.contiguous(), source.contiguous()
+        assert video.dim() == 5 and video.shape[0] == 1 and source.dim() == 4
+        _, C, F_, H, W = video.shape
+        assert source.shape[0] == F_ and source.shape[1] == C, "video and source disagree on frames / channels"
+        out = torch.empty(F_, H, W, C, dtype=torch.float32, device=self.torch_device)
+        self._check(self.lib.color_fix(self.h, _ptr(video), _ptr(source), _ptr(out), F_, C, H, W, source.shape[2], source.shape[3]),
+                    "color_fix")
+        return out
+
+    def adain_color_fix(self, target, source):
+        """adain_color_fix on its own (color_fix.py:15-29): target fp32 [F, H, W, C] in [0, 255] (tensor2vid result),
+        source fp32 [F, C, h, w] in [-1, 1]  ->  fp32 [F, H, W, C] in [0, 255]."""
+        self._chk_tensor(target, torch.float32); self._chk_tensor(source, torch.float32)
+        target, source = target.contiguous(), source.contiguous()
+        assert target.dim() == 4 and source.dim() == 4
+        F_, H, W, C = target.shape
+        assert source.shape[0] == F_ and source.shape[1] == C, "target and source disagree on frames / channels"
+        out = torch.empty(F_, H, W, C, dtype=torch.float32, device=self.torch_device)
+        self._check(self.lib.adain_color_fix(self.h, _ptr(target), _ptr(source), _ptr(out), F_, C, H, W, source.shape[2], source.shape[3]),
+                    "adain_color_fix")
+        return out
 
     def cast(self, x):
         self._chk_tensor(x, torch.float32)

@@ -17,6 +17,7 @@ from typing import Any, Dict
 import torch
 import torch.nn.functional as F
 
+from . import frames
 from .diffusion import GaussianDiffusion, noise_schedule
 from .geometry import make_chunks, pad_to_fit, sliding_windows_1d  # noqa: F401  (re-exported like the reference module)
 from .modules.unet_v2v import ControlledV2VUNet
@@ -80,6 +81,7 @@ class VideoToVideo_sr:
         generator.load_state_dict(sd, strict=False)
         generator.release_host_weights()
         self.generator = generator
+        frames.register_context(generator.ctx)   # the module-level frame helpers (colour fix) share this context
 
         # noise schedule (:46-53)
         sigmas = noise_schedule(schedule="logsnr_cosine_interp", n=1000, zero_terminal_snr=True, scale_min=2.0, scale_max=4.0)
@@ -132,10 +134,10 @@ class VideoToVideo_sr:
         (target_h, target_w) = input["target_res"]
         dev = self._tensor_device
 
-        video_data = F.interpolate(video_data.to(dev).float(), [target_h, target_w], mode="bilinear")
-        frames_num, _, h, w = video_data.shape
+        # F.interpolate(..., mode='bilinear') + F.pad(..., 'constant', 1) of the reference (:81-87) as one HIP pass
+        frames_num, h, w = video_data.shape[0], int(target_h), int(target_w)
         padding = pad_to_fit(h, w)
-        video_data = F.pad(video_data, padding, "constant", 1)
+        video_data = self.generator.ctx.resize_pad(video_data.to(dev, torch.float32), (h, w), padding, 1.0)
         video_data = video_data.unsqueeze(0)
         bs = 1
 

@@ -12,8 +12,9 @@ import torch
 
 base_path = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, base_path)
-from inference_utils import collate_fn, load_video, preprocess, save_video, tensor2vid  # noqa: E402
-from video_super_resolution.color_fix import adain_color_fix  # noqa: E402
+from inference_utils import collate_fn, load_video, preprocess, save_video, tensor2vid  # noqa: E402,F401
+from video_super_resolution.color_fix import adain_color_fix  # noqa: E402,F401  (re-exported like the reference script)
+from star_amd.frames import tensor2vid_color_fix  # noqa: E402
 from video_to_video.utils.seed import setup_seed  # noqa: E402
 from video_to_video.video_to_video_model import VideoToVideo_sr  # noqa: E402
 
@@ -43,10 +44,10 @@ class STAR:
         with torch.no_grad():
             data_tensor = collate_fn(pre_data, "cuda:0")
             output = self.model.test(data_tensor, total_noise_levels, steps=self.steps, solver_mode=self.solver_mode,
-                                     guide_scale=self.guide_scale, max_chunk_len=self.max_chunk_len)
-        output = tensor2vid(output)
-        output = adain_color_fix(output, video_data)
-        return save_video(output, self.result_dir, self.file_name, fps=input_fps)
+                                     guide_scale=self.guide_scale, max_chunk_len=self.max_chunk_len, return_device=True)
+            # tensor2vid + adain_color_fix (inference_sr.py:47-48) in one pass over the frames while they are still in HBM
+            output = tensor2vid_color_fix(output, data_tensor["video_data"], ctx=self.model.generator.ctx)
+        return save_video(output.cpu(), self.result_dir, self.file_name, fps=input_fps)
 
 
 def parse_args():
