@@ -17,7 +17,7 @@ emu: tools/hostemu/libstar_emu.so
 
 # attention kernels: no NaN-canonicalising v_max in front of every fmaxf on MFMA outputs (39 extra VALU per key tile);
 # masked scores are finite (-1e30 / -30000), so NaNs can only come from NaN inputs and propagate either way
-build/hip/attn.o: HIPFLAGS += -fno-honor-nans
+build/hip/attn.o: HIPFLAGS += -fno-honor-nans -fno-slp-vectorize
 build/hip/%.o: $(CSRC)/%.cpp $(wildcard $(CSRC)/*.h) include/star_hip.h
 	@mkdir -p build/hip
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@

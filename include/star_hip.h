@@ -65,7 +65,7 @@ typedef struct star_attn_desc {
   int64_t bsq, bsk, bsv, bso;        /* batch (frame) strides in elements; 0 = shared by all batches */
   int32_t Nq, Nk, heads, batch;
   float scale;
-  int32_t variant;                   /* 0 baseline, 1 v2, 2 v3 (use 2), 3 v3 with 4 waves/SIMD */
+  int32_t variant;                   /* kernel variant: 9 (v3 + lazy row maxima, fp32 row sums) is the product; 0-8 are A/B baselines */
 } star_attn_desc;
 int star_attn_fwd(star_ctx* ctx, const star_attn_desc* d);
 

@@ -1,4 +1,6 @@
 // attn.cpp -- launchers for the attention kernels (attn.h)
+#include <cstdio>
+#include <cstdlib>
 #include "ops.h"
 #include "attn.h"
 
@@ -16,9 +18,28 @@ static int launch_flash(Ctx* ctx, const AttnArgs& a) {
   const int BH = a.batch * a.heads;
   const long long nblk = 8LL * p.nqb * ((BH + 7) / 8);
   p.variant = a.variant;
+#ifndef STAR_HOSTEMU
+  if (std::getenv("STAR_DEBUG_OCC")) {   // resident workgroups per CU of the product kernel (debug aid)
+    static bool once = false;
+    if (!once) {
+      once = true;
+      int nb = -1;
+      hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, flash_attn_v3_kernel<T, 2, 1, 0, 1>, 256, 32768);
+      fprintf(stderr, "[star] flash_attn_v3<2,1,0,1>: %d workgroups of 256 threads per CU (err %d)\n", nb, (int)e);
+    }
+  }
+#endif
   if (a.variant == 0) STAR_LAUNCH((flash_attn_kernel<T>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);
   else if (a.variant == 1) STAR_LAUNCH((flash_attn_v2_kernel<T>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);
   else if (a.variant == 2) STAR_LAUNCH((flash_attn_v3_kernel<T, 2>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);
+  else if (a.variant == 6) STAR_LAUNCH((flash_attn_v3_kernel<T, 2, 1>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);
+  else if (a.variant == 7) STAR_LAUNCH((flash_attn_v3_kernel<T, 2, 2>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);
+  else if (a.variant == 8) STAR_LAUNCH((flash_attn_v3_kernel<T, 2, 3>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);
+  else if (a.variant == 9) STAR_LAUNCH((flash_attn_v3_kernel<T, 2, 1, 0, 1>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);
+  else if (a.variant == 11) STAR_LAUNCH((flash_attn_v3_kernel<T, 2, 1, 1>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);   // ablation probes of variant 6:
+  else if (a.variant == 12) STAR_LAUNCH((flash_attn_v3_kernel<T, 2, 1, 2>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);   // no exp / no PV MFMA /
+  else if (a.variant == 13) STAR_LAUNCH((flash_attn_v3_kernel<T, 2, 1, 3>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);   // no K/V staging /
+  else if (a.variant == 14) STAR_LAUNCH((flash_attn_v3_kernel<T, 2, 1, 4>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);   // no staging, no barriers
   else if (a.variant == 4) {   // software-pipelined, 128-row workgroups
     p.nqb = (a.Nq + 127) / 128;
     const long long nblk4 = 8LL * p.nqb * ((BH + 7) / 8);

@@ -432,7 +432,16 @@ flash_attn_v2_kernel(const AttnParams p) {
 // (K_aug[kv][0] = 1, Q_aug[q][0] = -m_q), so the accumulators already hold (score - max) and P = exp2(acc): 4 extra
 // MFMAs per tile replace 64 v_fma; m_q is kept exactly representable in T, a common row factor cancels in O = PV / l;
 // (2) row sums are taken from the packed (rounded) probabilities with v_dot2c (32 ops instead of 64 adds).
-template <class T, int NQ>   // NQ = 32-row query blocks per wave: 2 -> 2 waves/SIMD (256 VGPRs), 1 -> 4 waves/SIMD (128 VGPRs)
+// LAZY (variants 6 / 7): the row maxima are not computed at all on the common path.  P = exp2(score - running max) is
+// formed directly; its row sum (needed anyway) doubles as the overflow probe: a lane whose partial row sum stays <= 2^10
+// holds no P above 2^10, which is as good as a rescale threshold of 10.  Only when a sum exceeds that (or is inf/NaN)
+// does the wave recompute the tile's scores from the K tile still in LDS, take the exact maxima, move the running max
+// and redo the exponentials -- 38 v_max per tile traded for 9-18 extra MFMAs on the rare tiles where the max moves.
+// LAZY = 1: one probe per tile; LAZY = 2: one probe per 32-row query block, PV of block 0 beside the exponentials of block 1.
+// ROWSUM = 1: row sums as four chains of plain fp32 adds on the unrounded exponentials instead of v_dot2c on the packed P
+// (v_dot2c costs ~10 cycles beyond its issue slot beside MFMAs; attn.o is built with -fno-slp-vectorize so the adds stay
+// single-issue instead of being fused into v_pk_add_f32, which stalls beside MFMAs as well).
+template <class T, int NQ, int LAZY = 0, int ABL = 0, int ROWSUM = 0>   // NQ = 32-row query blocks per wave: 2 -> 2 waves/SIMD (256 VGPRs), 1 -> 4 waves/SIMD (128 VGPRs); ABL: ablation probes (bench only)
 STAR_GLOBAL void STAR_LAUNCH_BOUNDS(256, (NQ == 2 ? 2 : 4))
 flash_attn_v3_kernel(const AttnParams p) {
   constexpr int QW = 32 * NQ, QB = 4 * QW, KT = 64, TILE = KT * 128;
@@ -502,59 +511,74 @@ flash_attn_v3_kernel(const AttnParams p) {
   //          // always exactly representable in T (it is fed to the MFMA through Q_aug)
   const int nt = (p.Nk + KT - 1) / KT;
 
-  auto tile = [&](int t, auto mask_tag) {
+  auto tile = [&](int t, auto mask_tag, auto first_tag) {
     constexpr bool MASK = decltype(mask_tag)::value;
+    constexpr bool FIRST = decltype(first_tag)::value;   // LAZY == 3: the first key tile is peeled out of the loop
+    constexpr float LAZY_BIG = 1024.0f;
     const char* kbuf = smem + (t & 1) * 2 * TILE;
     const char* vbuf = kbuf + TILE;
-    // ---- S^T = K Q^T for both query blocks (16 MFMAs, 4 independent accumulators)
     f32x16 s[NQ][2];
+    // ---- S^T = K Q^T for query blocks [q_lo, q_hi) (8 + 1 MFMAs per block, independent accumulators)
+    auto scores = [&](int q_lo, int q_hi) {
 #pragma unroll
-    for (int a = 0; a < NQ; ++a)
+      for (int a = 0; a < NQ; ++a) {
+        if (a < q_lo || a >= q_hi) continue;
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
+        for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[a][kb][r] = 0.f;
-        s[a][kb] = mfma32<T>(kaug, qaug[a], s[a][kb]);      // -m_run broadcast over the 32 keys
+          for (int r = 0; r < 16; ++r) s[a][kb][r] = 0.f;
+          s[a][kb] = mfma32<T>(kaug, qaug[a], s[a][kb]);      // -m_run broadcast over the 32 keys
+        }
       }
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
+      for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        const vec<T, 8> kf = *reinterpret_cast<const vec<T, 8>*>(kbuf + swz_off(kb * 32 + lq, ks * 2 + h2));
+        for (int kb = 0; kb < 2; ++kb) {
+          const vec<T, 8> kf = *reinterpret_cast<const vec<T, 8>*>(kbuf + swz_off(kb * 32 + lq, ks * 2 + h2));
 #pragma unroll
-        for (int qi = 0; qi < NQ; ++qi) s[qi][kb] = mfma32<T>(kf, qf[qi][ks], s[qi][kb]);
-      }
-    if constexpr (MASK) {
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = t * KT + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
-          if (key >= p.Nk) {
-#pragma unroll
-            for (int qi = 0; qi < NQ; ++qi) s[qi][kb][r] = -1e30f;
+          for (int qi = 0; qi < NQ; ++qi) {
+            if (qi < q_lo || qi >= q_hi) continue;
+            s[qi][kb] = mfma32<T>(kf, qf[qi][ks], s[qi][kb]);
           }
         }
-    }
-    // ---- row maxima (already relative to the running max), one wave-uniform rescale decision
-    float m_tile[NQ];
+      if constexpr (MASK) {
 #pragma unroll
-    for (int qi = 0; qi < NQ; ++qi) {
-      float mx[4];
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int kb = g >> 1, o = (g & 1) * 8;
-        const float a0 = fmaxf(fmaxf(s[qi][kb][o], s[qi][kb][o + 1]), s[qi][kb][o + 2]);
-        const float a1 = fmaxf(fmaxf(s[qi][kb][o + 3], s[qi][kb][o + 4]), s[qi][kb][o + 5]);
-        mx[g] = fmaxf(fmaxf(a0, a1), fmaxf(s[qi][kb][o + 6], s[qi][kb][o + 7]));
+          for (int r = 0; r < 16; ++r) {
+            const int key = t * KT + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
+            if (key >= p.Nk) {
+#pragma unroll
+              for (int qi = 0; qi < NQ; ++qi) {
+                if (qi < q_lo || qi >= q_hi) continue;
+                s[qi][kb][r] = -1e30f;
+              }
+            }
+          }
       }
-      m_tile[qi] = pair_max(fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3])));
-    }
-    bool grow = m_tile[0] > RESCALE_THR;
-    if constexpr (NQ == 2) grow = grow || m_tile[NQ - 1] > RESCALE_THR;
-    if (t == 0 || wave_any(grow)) {
+    };
+    // ---- row maxima (already relative to the running max) of blocks [q_lo, q_hi)
+    float m_tile[NQ];
+    auto maxima = [&](int q_lo, int q_hi) {
 #pragma unroll
-      for (int qi = 0; qi < NQ; ++qi) {   // rare: move the running max, rescale O / l once, re-base this tile's scores
+      for (int qi = 0; qi < NQ; ++qi) {
+        if (qi < q_lo || qi >= q_hi) continue;
+        float mx[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int kb = g >> 1, o = (g & 1) * 8;
+          const float a0 = fmaxf(fmaxf(s[qi][kb][o], s[qi][kb][o + 1]), s[qi][kb][o + 2]);
+          const float a1 = fmaxf(fmaxf(s[qi][kb][o + 3], s[qi][kb][o + 4]), s[qi][kb][o + 5]);
+          mx[g] = fmaxf(fmaxf(a0, a1), fmaxf(s[qi][kb][o + 6], s[qi][kb][o + 7]));
+        }
+        m_tile[qi] = pair_max(fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3])));
+      }
+    };
+    // ---- rare: move the running max of blocks [q_lo, q_hi), rescale O / l once, re-base this tile's scores
+    auto rebase = [&](int q_lo, int q_hi) {
+#pragma unroll
+      for (int qi = 0; qi < NQ; ++qi) {
+        if (qi < q_lo || qi >= q_hi) continue;
         const float inc = (t == 0) ? m_tile[qi] : fmaxf(m_tile[qi], 0.f);
         const float m_new = to_f32<T>(from_f32<T>(m_run[qi] + inc));
         const float delta = m_new - m_run[qi];
@@ -571,62 +595,260 @@ flash_attn_v3_kernel(const AttnParams p) {
           for (int r = 0; r < 16; ++r) s[qi][kb][r] -= delta;
         if (h2 == 0) qaug[qi][0] = from_f32<T>(-m_new);
       }
-    }
-    // ---- straight-line: P0 ; PV0 beside P1 ; PV1
+    };
     vec<T, 8> pf[NQ][4];
+    float lsum[NQ];
     auto expo = [&](int qi) {
-      float ls0 = 0.f, ls1 = 0.f;
+      float ls0 = 0.f, ls1 = 0.f, ls2 = 0.f, ls3 = 0.f;
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           vec<T, 8> pk;
+          if constexpr (ROWSUM == 1) {
+            float e8[8];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) pk[e] = from_f32<T>(fast_exp2(s[qi][kb][8 * u + e]));
+            for (int e = 0; e < 8; ++e) e8[e] = fast_exp2(s[qi][kb][8 * u + e]);
 #pragma unroll
-          for (int e = 0; e < 8; e += 4) {   // row sum of the ROUNDED probabilities (what PV multiplies), 2 per v_dot2c
-            vec<T, 2> a, b2;
-            a[0] = pk[e]; a[1] = pk[e + 1]; b2[0] = pk[e + 2]; b2[1] = pk[e + 3];
-            ls0 = dot2_ones<T>(a, ls0);
-            ls1 = dot2_ones<T>(b2, ls1);
+            for (int e = 0; e < 8; e += 4) {
+              ls0 += e8[e]; ls1 += e8[e + 1];
+              ls2 += e8[e + 2]; ls3 += e8[e + 3];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pk[e] = from_f32<T>(e8[e]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pk[e] = from_f32<T>(ABL == 1 ? s[qi][kb][8 * u + e] * 0.001f : fast_exp2(s[qi][kb][8 * u + e]));
+#pragma unroll
+            for (int e = 0; e < 8; e += 4) {   // row sum of the ROUNDED probabilities (what PV multiplies), 2 per v_dot2c
+              vec<T, 2> a, b2;
+              a[0] = pk[e]; a[1] = pk[e + 1]; b2[0] = pk[e + 2]; b2[1] = pk[e + 3];
+              ls0 = dot2_ones<T>(a, ls0);
+              ls1 = dot2_ones<T>(b2, ls1);
+            }
           }
           pf[qi][kb * 2 + u] = pk;
         }
-      l_run[qi] += ls0 + ls1;
+      lsum[qi] = (ls0 + ls1) + (ls2 + ls3);
     };
+    auto pv = [&](int q_lo, int q_hi) {
 #pragma unroll
-    for (int qi = 0; qi < NQ; ++qi) expo(qi);
+      for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
-    for (int tt = 0; tt < 4; ++tt)
+        for (int db = 0; db < 2; ++db) {
+          const vec<T, 8> vf = load_vt_frag<T>(vbuf, tt * 16, db, lane);
 #pragma unroll
-      for (int db = 0; db < 2; ++db) {
-        const vec<T, 8> vf = load_vt_frag<T>(vbuf, tt * 16, db, lane);
+          for (int qi = 0; qi < NQ; ++qi) {
+            if (qi < q_lo || qi >= q_hi) continue;
+            if constexpr (ABL == 2) { oacc[qi][db][tt] += to_f32<T>(pf[qi][tt][db]) + to_f32<T>(vf[0]); continue; }
+            oacc[qi][db] = mfma32<T>(vf, pf[qi][tt], oacc[qi][db]);
+          }
+        }
+    };
+
+    if constexpr (LAZY == 0) {
+      scores(0, NQ);
+      maxima(0, NQ);
+      bool grow = m_tile[0] > RESCALE_THR;
+      if constexpr (NQ == 2) grow = grow || m_tile[NQ - 1] > RESCALE_THR;
+      if (t == 0 || wave_any(grow)) rebase(0, NQ);   // one wave-uniform rescale decision
+      // ---- straight-line: P0 ; PV0 beside P1 ; PV1
 #pragma unroll
-        for (int qi = 0; qi < NQ; ++qi) oacc[qi][db] = mfma32<T>(vf, pf[qi][tt], oacc[qi][db]);
-      }
+      for (int qi = 0; qi < NQ; ++qi) { expo(qi); l_run[qi] += lsum[qi]; }
+      pv(0, NQ);
 #ifndef STAR_HOSTEMU
-    // interleave: the first 8 PV MFMAs (they only need P0) beside the VALU of expo(1)
-    if constexpr (NQ == 2) for (int i = 0; i < 8; ++i) {
-      STAR_SCHED_GROUP(0x008, 1, 0);   // 1 MFMA
-      STAR_SCHED_GROUP(0x100, 2, 0);   // 2 DS reads
-      STAR_SCHED_GROUP(0x002, 12, 0);  // 12 VALU
-    }
+      // interleave: the first 8 PV MFMAs (they only need P0) beside the VALU of expo(1)
+      if constexpr (NQ == 2) for (int i = 0; i < 8; ++i) {
+        STAR_SCHED_GROUP(0x008, 1, 0);   // 1 MFMA
+        STAR_SCHED_GROUP(0x100, 2, 0);   // 2 DS reads
+        STAR_SCHED_GROUP(0x002, 12, 0);  // 12 VALU
+      }
 #endif
+    } else if constexpr (LAZY == 1) {
+      scores(0, NQ);
+      if (t == 0) { maxima(0, NQ); rebase(0, NQ); }
+      bool bad = false;
+#pragma unroll
+      for (int qi = 0; qi < NQ; ++qi) { expo(qi); bad = bad || !(lsum[qi] <= LAZY_BIG); }
+      if (wave_any(bad)) {          // some P is large (or overflowed): exact maxima from recomputed scores, then redo
+        scores(0, NQ);
+        maxima(0, NQ);
+        rebase(0, NQ);
+#pragma unroll
+        for (int qi = 0; qi < NQ; ++qi) expo(qi);
+      }
+#pragma unroll
+      for (int qi = 0; qi < NQ; ++qi) l_run[qi] += lsum[qi];
+      pv(0, NQ);
+    } else if constexpr (LAZY == 3) {
+      // key-half pipeline: the tile is processed as two 32-key halves; the exponentials of one half run beside the
+      // MFMAs of the other (QK of half 1 beside exp of half 0, PV of half 0 beside exp of half 1).  K / V fragments are
+      // still shared by both query blocks, so LDS traffic is unchanged.
+      auto scores_kb = [&](int kb) {
+#pragma unroll
+        for (int a = 0; a < NQ; ++a) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s[a][kb][r] = 0.f;
+          s[a][kb] = mfma32<T>(kaug, qaug[a], s[a][kb]);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const vec<T, 8> kf = *reinterpret_cast<const vec<T, 8>*>(kbuf + swz_off(kb * 32 + lq, ks * 2 + h2));
+#pragma unroll
+          for (int qi = 0; qi < NQ; ++qi) s[qi][kb] = mfma32<T>(kf, qf[qi][ks], s[qi][kb]);
+        }
+        if constexpr (MASK) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = t * KT + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
+            if (key >= p.Nk) {
+#pragma unroll
+              for (int qi = 0; qi < NQ; ++qi) s[qi][kb][r] = -1e30f;
+            }
+          }
+        }
+      };
+      float lk[NQ];
+      auto expo_kb = [&](int kb) {
+#pragma unroll
+        for (int qi = 0; qi < NQ; ++qi) {
+          float ls0 = 0.f, ls1 = 0.f;
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            vec<T, 8> pk;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pk[e] = from_f32<T>(fast_exp2(s[qi][kb][8 * u + e]));
+#pragma unroll
+            for (int e = 0; e < 8; e += 4) {
+              vec<T, 2> a, b2;
+              a[0] = pk[e]; a[1] = pk[e + 1]; b2[0] = pk[e + 2]; b2[1] = pk[e + 3];
+              ls0 = dot2_ones<T>(a, ls0);
+              ls1 = dot2_ones<T>(b2, ls1);
+            }
+            pf[qi][kb * 2 + u] = pk;
+          }
+          lk[qi] = ls0 + ls1;
+        }
+      };
+      auto pv_kb = [&](int kb) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int db = 0; db < 2; ++db) {
+            const vec<T, 8> vf = load_vt_frag<T>(vbuf, (kb * 2 + u) * 16, db, lane);
+#pragma unroll
+            for (int qi = 0; qi < NQ; ++qi) oacc[qi][db] = mfma32<T>(vf, pf[qi][kb * 2 + u], oacc[qi][db]);
+          }
+      };
+      auto maxima_kb = [&](int kb) {
+#pragma unroll
+        for (int qi = 0; qi < NQ; ++qi) {
+          float mx[2];
+#pragma unroll
+          for (int g = 0; g < 2; ++g) {
+            const int o = g * 8;
+            const float a0 = fmaxf(fmaxf(s[qi][kb][o], s[qi][kb][o + 1]), s[qi][kb][o + 2]);
+            const float a1 = fmaxf(fmaxf(s[qi][kb][o + 3], s[qi][kb][o + 4]), s[qi][kb][o + 5]);
+            mx[g] = fmaxf(fmaxf(a0, a1), fmaxf(s[qi][kb][o + 6], s[qi][kb][o + 7]));
+          }
+          m_tile[qi] = pair_max(fmaxf(mx[0], mx[1]));
+        }
+      };
+      auto probe = [&]() {
+        bool bad = false;
+#pragma unroll
+        for (int qi = 0; qi < NQ; ++qi) bad = bad || !(lk[qi] <= LAZY_BIG);
+        return wave_any(bad);
+      };
+      if constexpr (FIRST) {              // the first tile sets the running max from exact maxima
+        scores(0, NQ);
+        maxima(0, NQ);
+        rebase(0, NQ);
+#pragma unroll
+        for (int qi = 0; qi < NQ; ++qi) { expo(qi); l_run[qi] += lsum[qi]; }
+        pv(0, NQ);
+      } else {
+        scores_kb(0);
+        scores_kb(1);
+        expo_kb(0);
+#if !defined(STAR_HOSTEMU) && defined(STAR_ATTN_V8_HINTS)
+        for (int i = 0; i < 10; ++i) {      // QK of half 1 beside the exponentials of half 0
+          STAR_SCHED_GROUP(0x008, 1, 0);    // 1 MFMA
+          STAR_SCHED_GROUP(0x002, 8, 0);    // 8 VALU
+        }
+#endif
+        if (probe()) { scores_kb(0); maxima_kb(0); rebase(0, NQ); expo_kb(0); }
+#pragma unroll
+        for (int qi = 0; qi < NQ; ++qi) l_run[qi] += lk[qi];
+        pv_kb(0);
+        expo_kb(1);
+#if !defined(STAR_HOSTEMU) && defined(STAR_ATTN_V8_HINTS)
+        for (int i = 0; i < 8; ++i) {       // PV of half 0 beside the exponentials of half 1
+          STAR_SCHED_GROUP(0x008, 1, 0);
+          STAR_SCHED_GROUP(0x002, 10, 0);
+        }
+#endif
+        if (probe()) { scores_kb(1); maxima_kb(1); rebase(0, NQ); expo_kb(1); }
+#pragma unroll
+        for (int qi = 0; qi < NQ; ++qi) l_run[qi] += lk[qi];
+        pv_kb(1);
+      }
+    } else {
+      scores(0, NQ);
+      if (t == 0) { maxima(0, NQ); rebase(0, NQ); }
+#pragma unroll
+      for (int qi = 0; qi < NQ; ++qi) {
+        if (qi == 0) expo(0);
+        if (wave_any(!(lsum[qi] <= LAZY_BIG))) {
+          scores(qi, qi + 1);
+          maxima(qi, qi + 1);
+          rebase(qi, qi + 1);
+          expo(qi);
+        }
+        l_run[qi] += lsum[qi];
+        pv(qi, qi + 1);                    // PV of this block ...
+        if (qi + 1 < NQ) expo(qi + 1);     // ... beside the exponentials of the next one
+#ifndef STAR_HOSTEMU
+        if (qi + 1 < NQ) for (int i = 0; i < 8; ++i) {
+          STAR_SCHED_GROUP(0x008, 1, 0);   // 1 MFMA
+          STAR_SCHED_GROUP(0x100, 2, 0);   // 2 DS reads
+          STAR_SCHED_GROUP(0x002, 12, 0);  // 12 VALU
+        }
+#endif
+      }
+    }
   };
 
   stage(0, 0);
   const bool has_tail = (p.Nk & (KT - 1)) != 0;
   const int nfull = has_tail ? nt - 1 : nt;
-  for (int t = 0; t < nfull; ++t) {
-    glds_wait();
-    block_sync();
-    if (t + 1 < nt) stage(t + 1, (t + 1) & 1);
-    tile(t, std::false_type{});
-  }
-  if (has_tail) {
-    glds_wait();
-    block_sync();
-    tile(nt - 1, std::true_type{});
+  if constexpr (LAZY == 3) {
+    if (nfull > 0) {
+      glds_wait(); block_sync();
+      if (1 < nt) stage(1, 1);
+      tile(0, std::false_type{}, std::true_type{});
+    }
+    for (int t = 1; t < nfull; ++t) {
+      glds_wait(); block_sync();
+      if (t + 1 < nt) stage(t + 1, (t + 1) & 1);
+      tile(t, std::false_type{}, std::false_type{});
+    }
+    if (has_tail) {
+      glds_wait(); block_sync();
+      if (nt == 1) tile(0, std::true_type{}, std::true_type{});
+      else tile(nt - 1, std::true_type{}, std::false_type{});
+    }
+  } else {
+    for (int t = 0; t < nfull; ++t) {
+      if (ABL < 4 || t < 2) { glds_wait(); block_sync(); }
+      if (t + 1 < nt && (ABL < 3 || t == 0)) stage(t + 1, (t + 1) & 1);
+      tile(t, std::false_type{}, std::false_type{});
+    }
+    if (has_tail) {
+      glds_wait();
+      block_sync();
+      tile(nt - 1, std::true_type{}, std::false_type{});
+    }
   }
 
 #pragma unroll

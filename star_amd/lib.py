@@ -235,7 +235,7 @@ class Context:
         self._check(self.lib.gemm(self.h, ctypes.byref(d)), "gemm")
         return out
 
-    def attention(self, q, k, v, heads, out=None, scale=None, variant=2):
+    def attention(self, q, k, v, heads, out=None, scale=None, variant=9):
         """softmax(q k^T * scale) v per (batch, head).  q: [B, Nq, heads*64]; k, v: [B or 1, Nk, heads*64]
         (a leading dim of 1 is shared by all batches).  Views with a row stride are fine (fused QKV buffers)."""
         for t in (q, k, v):

@@ -144,7 +144,7 @@ def ref_attention(q, k, v, heads):
     return o.transpose(1, 2).reshape(B, -1, heads * 64)
 
 
-@pytest.mark.parametrize("variant", [2, 4, 5])
+@pytest.mark.parametrize("variant", [2, 4, 5, 6, 7, 8, 9])
 @pytest.mark.parametrize("B,heads,Nq,Nk", [(2, 2, 300, 300), (1, 5, 80, 80), (3, 1, 257, 64), (1, 2, 64, 1), (9, 1, 33, 130), (1, 1, 130, 129)])
 def test_flash_attention_self(ctx, dtype, B, heads, Nq, Nk, variant):
     """spatial self-attention (unet_v2v.py:472 -> :184) on a fused QKV buffer, ragged q/k tails."""
@@ -169,7 +169,7 @@ def test_flash_attention_cross_77(ctx, dtype):
     assert_close(out, ref_attention(q, kv[..., :128], kv[..., 128:], heads), dtype, what="flash cross")
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
 def test_flash_attention_variants_agree(ctx, dtype, variant):
     """all kernel variants (baseline / v2 / v3 with the augmented-k running max) against the fp32 reference, incl. a
     ragged key tail, strongly negative logits in tile 0 and a late spike that forces the rescale branch."""
@@ -185,7 +185,8 @@ def test_flash_attention_variants_agree(ctx, dtype, variant):
     assert_close(out, ref_attention(q, k, v, heads), dtype, scale=6.0, what=f"flash variant {variant}")
 
 
-def test_flash_attention_forced_rescale(ctx, dtype):
+@pytest.mark.parametrize("variant", [2, 6, 7, 8, 9])
+def test_flash_attention_forced_rescale(ctx, dtype, variant):
     """a key spike late in the sequence forces the online-softmax rescale branch with a large max jump."""
     g = torch.Generator().manual_seed(11)
     B, heads, N = 1, 1, 400
@@ -195,8 +196,26 @@ def test_flash_attention_forced_rescale(ctx, dtype):
     k[:, 333] = q[:, 7] * 4.0     # q.k ~ 4*64 = 256 against O(8) elsewhere
     k[:, 2] = q[:, 100] * 3.0     # and an early spike that later tiles must not disturb
     q, k, v = q.to(dtype), k.to(dtype), v.to(dtype)
-    out = ctx.attention(dev(ctx, q), dev(ctx, k), dev(ctx, v), heads)
+    out = ctx.attention(dev(ctx, q), dev(ctx, k), dev(ctx, v), heads, variant=variant)
     assert_close(out, ref_attention(q, k, v, heads), dtype, what="flash rescale")
+
+
+@pytest.mark.parametrize("variant", [2, 6, 7, 8, 9])
+def test_flash_attention_growing_max(ctx, dtype, variant):
+    """scores that keep growing along the key axis (every tile moves the maximum by several binades, some by more than
+    the fp16 exponent range) and a first tile far below everything that follows: the lazy-max variants must take their
+    recompute path tile after tile and still match."""
+    g = torch.Generator().manual_seed(31)
+    B, heads, N = 1, 2, 520
+    q = torch.randn(B, N, 128, generator=g)
+    k = torch.randn(B, N, 128, generator=g) * 0.2
+    v = torch.randn(B, N, 128, generator=g)
+    ramp = torch.linspace(-3.0, 6.0, N)                      # key j adds ramp[j] * |q|^2 / 8 to the logit
+    k = k + q.mean(1, keepdim=True) * 0 + (ramp[None, :, None] * torch.nn.functional.normalize(q[:, :1], dim=-1) * 3.0)
+    k[:, 450, :64] = q[:, 5, :64] * 6.0                      # one jump of > 16 binades for a single row
+    q, k, v = q.to(dtype), k.to(dtype), v.to(dtype)
+    out = ctx.attention(dev(ctx, q), dev(ctx, k), dev(ctx, v), heads, variant=variant)
+    assert_close(out, ref_attention(q, k, v, heads), dtype, scale=6.0, what=f"flash growing max v{variant}")
 
 
 @pytest.mark.parametrize("Fr,HW,heads", [(5, 7, 2), (32, 9, 1), (40, 5, 2), (16, 130, 5), (1, 4, 1)])
