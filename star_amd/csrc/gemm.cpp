@@ -16,7 +16,8 @@ static int launch_gemm_f(Ctx* ctx, const GemmArgs& a) {
   // 2 stages x 64 k, or PIPE ring slots x 32 k; never less than the epilogue's per-wave staging blocks
   constexpr size_t smem_loop = PIPE ? (size_t)PIPE * (BM + BN) * 64 : 2 * (size_t)(BM + BN) * 128;
   constexpr size_t smem_epi = (size_t)WM * WN * 32 * (BN / WN * 2 + 8);
-  constexpr size_t smem = smem_loop > smem_epi ? smem_loop : smem_epi;
+  static_assert(smem_epi <= smem_loop, "the epilogue's staging blocks must fit under the bias slice");
+  constexpr size_t smem = smem_loop + (size_t)BN * sizeof(float);   // + this tile's bias slice
   dim3 grid((unsigned)(p.tiles_m * p.tiles_n)), block(WM * WN * 64);
   switch (a.mode) {
     case A_PLAIN: STAR_LAUNCH((gemm_kernel<T, BM, BN, WM, WN, A_PLAIN, MINW, F32OUT, STAGGER, 0, PIPE>), grid, block, smem, ctx->stream, p); break;
@@ -41,6 +42,7 @@ static int launch_gemm(Ctx* ctx, const GemmArgs& a) {
     const bool geglu = (a.epi & EPI_GEGLU) != 0;
     if (a.M <= 4096 && a.N <= 1024) tile = 3;                          // small problems: more, smaller tiles
     else if (!geglu && a.N % 320 == 0) tile = 2;                        // 320 / 640 / 960 / 1280 / 1920-wide layers
+    else if (geglu && a.K <= 320 && a.mode == A_PLAIN) tile = 9;        // short K, GELU-heavy epilogue: two workgroups per CU overlap it
     else if (a.N <= 128) tile = 4;
     else tile = 1;
   }
@@ -66,7 +68,7 @@ static int launch_gemm(Ctx* ctx, const GemmArgs& a) {
     p.M = a.M; p.N = a.N; p.K = a.K; p.lda = a.lda; p.ldc = a.ldc; p.ldr = a.ldr; p.epi = a.epi;
     p.tiles_m = (a.M + 255) / 256; p.tiles_n = (a.N + 255) / 256;
     dim3 grid((unsigned)(p.tiles_m * p.tiles_n)), block(512);
-    const size_t smem = 2 * (size_t)512 * 128;
+    const size_t smem = 2 * (size_t)512 * 128 + 256 * sizeof(float);
     if (tile == 11) STAR_LAUNCH((gemm_kernel<T, 256, 256, 4, 2, A_PLAIN, 2, false, false, 1>), grid, block, smem, ctx->stream, p);
     if (tile == 12) STAR_LAUNCH((gemm_kernel<T, 256, 256, 4, 2, A_PLAIN, 2, false, false, 2>), grid, block, smem, ctx->stream, p);
     if (tile == 13) STAR_LAUNCH((gemm_kernel<T, 256, 256, 4, 2, A_PLAIN, 2, false, false, 3>), grid, block, smem, ctx->stream, p);

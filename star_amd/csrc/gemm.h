@@ -64,6 +64,7 @@ gemm_kernel(const GemmParams p) {
   static_assert(NT % 8 == 0, "");
   constexpr int A_STAGE = BM * 128, W_STAGE = BN * 128;
   constexpr int STAGE = A_STAGE + W_STAGE;
+  constexpr int SMEM_LOOP = PIPE ? PIPE * (BM + BN) * 64 : 2 * STAGE;   // bytes of the main loop's buffers; bias[BN] fp32 follows
 
   char* smem = dyn_smem();
   const int tid = threadIdx.x;
@@ -81,6 +82,11 @@ gemm_kernel(const GemmParams p) {
   }
   const int tile_m = bid / p.tiles_n, tile_n = bid % p.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  if constexpr (!F32OUT) {   // this tile's bias slice, read from LDS in the epilogue (visible after the main loop's barriers)
+    float* bl = reinterpret_cast<float*>(smem + SMEM_LOOP);
+    for (int n = tid; n < BN; n += NT) bl[n] = ((p.epi & EPI_BIAS) && n0 + n < p.N) ? p.bias[n0 + n] : 0.f;
+  }
 
   const T* __restrict__ Ag = (const T*)p.A;
   const T* __restrict__ Wg = (const T*)p.W;
@@ -390,17 +396,55 @@ gemm_kernel(const GemmParams p) {
         }
     }
   } else {
+    // The output of the K = 320 / 640 layers is what bounds them (C is 2-8x the bytes of A), so the epilogue is built for
+    // the write stream: no global load is ever issued behind a store (vmcnt retires in order, a load behind stores waits
+    // for their HBM write latency) -- the bias comes from LDS, the residual chunks of a 32-row block are all read before
+    // the first store of the previous block is issued -- and the barriers between the staging steps do not drain vmcnt.
     const bool geglu = (p.epi & EPI_GEGLU) != 0;
     const int out_wtn = geglu ? WTN / 2 : WTN;       // output columns per wave
     const int out_n0 = geglu ? (n0 + wn * WTN) / 2 : (n0 + wn * WTN);
     const int N_out = geglu ? p.N / 2 : p.N;
     constexpr int pitch = WTN * 2 + 8;                // bytes; (pitch/4) % 4 == 2 -> conflict-free b64 writes
+    constexpr int RUN = (4 * WTN + 63) / 64;          // 16-B chunks per lane and 32-row block
+    const float* bias_lds = reinterpret_cast<const float*>(smem + SMEM_LOOP) + wn * WTN;
     block_sync();                                     // all MFMA reads of the stages are done
     char* my = smem + wave * (32 * pitch);
-    const float* __restrict__ bias = p.bias;
     const int cpr = out_wtn / 8;                      // 16-B chunks per row
     const int nchunks = 32 * cpr;
 
+    vec<T, 8> rv[TM][RUN];
+    auto load_res = [&](int i) {
+#pragma unroll
+      for (int u = 0; u < RUN; ++u) {
+        const int q = lane + 64 * u;
+        const int row = q / cpr, cc = q - row * cpr;
+        const int m = m0 + wm * WTM + i * 32 + row, n = out_n0 + cc * 8;
+        if (q < nchunks && m < p.M && n < N_out)
+          rv[i][u] = *reinterpret_cast<const vec<T, 8>*>((const T*)p.res + (size_t)m * p.ldr + n);
+      }
+    };
+    auto store_block = [&](int i) {
+#pragma unroll
+      for (int u = 0; u < RUN; ++u) {
+        const int q = lane + 64 * u;
+        const int row = q / cpr, cc = q - row * cpr;
+        const int m = m0 + wm * WTM + i * 32 + row, n = out_n0 + cc * 8;
+        if (q < nchunks && m < p.M && n < N_out) {
+          const vec<T, 4> lo = *reinterpret_cast<const vec<T, 4>*>(my + row * pitch + cc * 16);
+          const vec<T, 4> hi = *reinterpret_cast<const vec<T, 4>*>(my + row * pitch + cc * 16 + 8);
+          vec<T, 8> ov;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { ov[e] = lo[e]; ov[4 + e] = hi[e]; }
+          if (p.epi & EPI_RES) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ov[e] = from_f32<T>(to_f32<T>(ov[e]) + to_f32<T>(rv[i][u][e]));
+          }
+          *reinterpret_cast<vec<T, 8>*>((T*)p.C + (size_t)m * p.ldc + n) = ov;
+        }
+      }
+    };
+
+    if (p.epi & EPI_RES) load_res(0);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       // ---- registers -> LDS (T, row-major [32][out_wtn])
@@ -410,20 +454,16 @@ gemm_kernel(const GemmParams p) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int nl = j * 32 + 8 * g + 4 * fhalf;  // local n within the wave tile (pre-GEGLU)
-          int ng = n0 + wn * WTN + nl;
           f32x4 v;
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = acc[i][j][g * 4 + e];
-          if (ng > p.N - 4) ng = p.N - 4;             // columns past N are never stored; keep the bias load in range
-          if (p.epi & EPI_BIAS) v += *reinterpret_cast<const f32x4*>(bias + ng);
+          v += *reinterpret_cast<const f32x4*>(bias_lds + nl);   // zeros when the layer has no bias
           int ncol = nl;
           if (geglu) {
             f32x4 gt;
 #pragma unroll
             for (int e = 0; e < 4; ++e) gt[e] = acc[i][(j + 1 < TN) ? j + 1 : j][g * 4 + e];
-            int ngg = ng + 32;
-            if (ngg > p.N - 4) ngg = p.N - 4;
-            if (p.epi & EPI_BIAS) gt += *reinterpret_cast<const f32x4*>(bias + ngg);
+            gt += *reinterpret_cast<const f32x4*>(bias_lds + nl + 32);
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = v[e] * gelu_erf(gt[e]);
             ncol = (j >> 1) * 32 + 8 * g + 4 * fhalf;
@@ -434,27 +474,11 @@ gemm_kernel(const GemmParams p) {
           *reinterpret_cast<vec<T, 4>*>(my + frow * pitch + ncol * 2) = o;
         }
       }
-      block_sync();
-      // ---- LDS -> global: whole 16-B chunks along rows (+ residual)
-      for (int q = lane; q < nchunks; q += 64) {
-        const int row = q / cpr, cc = q - row * cpr;
-        const int m = m0 + wm * WTM + i * 32 + row;
-        const int n = out_n0 + cc * 8;
-        if (m < p.M && n < N_out) {
-          const vec<T, 4> lo = *reinterpret_cast<const vec<T, 4>*>(my + row * pitch + cc * 16);
-          const vec<T, 4> hi = *reinterpret_cast<const vec<T, 4>*>(my + row * pitch + cc * 16 + 8);
-          vec<T, 8> ov;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { ov[e] = lo[e]; ov[4 + e] = hi[e]; }
-          if (p.epi & EPI_RES) {
-            const vec<T, 8> rv = *reinterpret_cast<const vec<T, 8>*>((const T*)p.res + (size_t)m * p.ldr + n);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) ov[e] = from_f32<T>(to_f32<T>(ov[e]) + to_f32<T>(rv[e]));
-          }
-          *reinterpret_cast<vec<T, 8>*>((T*)p.C + (size_t)m * p.ldc + n) = ov;
-        }
-      }
-      block_sync();
+      barrier_keep_dma();
+      if ((p.epi & EPI_RES) && i + 1 < TM) load_res(i + 1);   // the next block's residual, ahead of this block's stores
+      // ---- LDS -> global: whole 16-B chunks along rows (+ residual, already in registers)
+      store_block(i);
+      barrier_keep_dma();
     }
   }
 }
