@@ -21,12 +21,13 @@ from video_to_video.video_to_video_model import VideoToVideo_sr  # noqa: E402
 
 class STAR:
     def __init__(self, result_dir="./results/", file_name="000_video.mp4", model_path="", solver_mode="fast", steps=15,
-                 guide_scale=7.5, upscale=4, max_chunk_len=32, vae_path="", dtype="f16", negative_embedding=""):
+                 guide_scale=7.5, upscale=4, max_chunk_len=32, vae_path="", dtype="f16", negative_embedding="", **model_opts):
         self.model_path, self.result_dir, self.file_name = model_path, result_dir, file_name
         os.makedirs(self.result_dir, exist_ok=True)
         opt = dict(model_path=model_path, vae_path=vae_path, dtype={"f16": torch.float16, "bf16": torch.bfloat16}[dtype])
         if negative_embedding:
             opt["negative_y"] = torch.load(negative_embedding)
+        opt.update(model_opts)      # e.g. unet_config / vae_config of a reduced model, text_encoder, rng
         self.model = VideoToVideo_sr(opt)
         steps = 15 if solver_mode == "fast" else steps       # reference: `fast` forces 15 (inference_sr.py:43)
         self.solver_mode, self.steps, self.guide_scale = solver_mode, steps, guide_scale
