@@ -30,8 +30,8 @@ static int gn_t(Ctx* ctx, const void* x, int ldx, void* y, int ldy, const float*
   STAR_LAUNCH((gn_stats_kernel<T>), grid, dim3(nthreads), (size_t)nthreads * 64, ctx->stream, sp);
   GnFinalizeParams fp{partial.as<double>(), gamma, beta, ab.as<float>(), C, nstat, nslab, (double)rows_per_stat * (C / 32), eps};
   STAR_LAUNCH(gn_finalize_kernel, dim3((unsigned)((nstat * 32 + 3) / 4)), dim3(256), (size_t)0, ctx->stream, fp);
-  GnApplyParams ap{x, y, ab.as<float>(), ldx, ldy, C, rows, rows_per_stat, silu ? 1 : 0};
-  STAR_LAUNCH((gn_apply_kernel<T>), dim3(ew_grid((long long)rows * CC8)), dim3(256), (size_t)0, ctx->stream, ap);
+  GnApplyParams ap{x, y, ab.as<float>(), ldx, ldy, C, rows_per_stat, slab, silu ? 1 : 0};
+  STAR_LAUNCH((gn_apply_kernel<T>), grid, dim3(nthreads), (size_t)0, ctx->stream, ap);
   return 0;
 }
 

@@ -109,21 +109,29 @@ STAR_GLOBAL void gn_finalize_kernel(const GnFinalizeParams p) {
 }
 
 struct GnApplyParams {
-  const void* x; void* y; const float* ab; int ldx, ldy, C; int rows; int rows_per_stat; int silu;
+  const void* x; void* y; const float* ab; int ldx, ldy, C; int rows_per_stat; int slab; int silu;
 };
+// grid (slab, stat), CC8 x RL threads like gn_stats_kernel: a thread owns one 8-channel chunk, keeps its 16 affine
+// coefficients in registers and walks the rows of the slab (no index divisions, no coefficient re-loads in the loop)
 template <class T>
 STAR_GLOBAL void gn_apply_kernel(const GnApplyParams p) {
   const int CC8 = p.C >> 3;
-  const long long total = (long long)p.rows * CC8;
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  auto one = [&](long long q, const vec<T, 8>& v) {
-    const int row = (int)(q / CC8), cc = (int)(q - (long long)row * CC8);
-    const int stat = row / p.rows_per_stat;
-    const float* ab = p.ab + 2 * ((size_t)stat * p.C + cc * 8);
-    const f32x4 ab0 = *reinterpret_cast<const f32x4*>(ab), ab1 = *reinterpret_cast<const f32x4*>(ab + 4),
-                ab2 = *reinterpret_cast<const f32x4*>(ab + 8), ab3 = *reinterpret_cast<const f32x4*>(ab + 12);
-    const float av[8] = {ab0[0], ab0[2], ab1[0], ab1[2], ab2[0], ab2[2], ab3[0], ab3[2]};
-    const float bv[8] = {ab0[1], ab0[3], ab1[1], ab1[3], ab2[1], ab2[3], ab3[1], ab3[3]};
+  const int t = threadIdx.x;
+  const int RL = blockDim.x / CC8;
+  const int cc = t % CC8, rl = t / CC8;
+  if (rl >= RL) return;
+  const int stat = blockIdx.y;
+  const int r0 = blockIdx.x * p.slab;
+  int r1 = r0 + p.slab;
+  if (r1 > p.rows_per_stat) r1 = p.rows_per_stat;
+  const float* ab = p.ab + 2 * ((size_t)stat * p.C + cc * 8);
+  const f32x4 ab0 = *reinterpret_cast<const f32x4*>(ab), ab1 = *reinterpret_cast<const f32x4*>(ab + 4),
+              ab2 = *reinterpret_cast<const f32x4*>(ab + 8), ab3 = *reinterpret_cast<const f32x4*>(ab + 12);
+  const float av[8] = {ab0[0], ab0[2], ab1[0], ab1[2], ab2[0], ab2[2], ab3[0], ab3[2]};
+  const float bv[8] = {ab0[1], ab0[3], ab1[1], ab1[3], ab2[1], ab2[3], ab3[1], ab3[3]};
+  const T* __restrict__ xb = (const T*)p.x + ((size_t)stat * p.rows_per_stat) * p.ldx + cc * 8;
+  T* __restrict__ yb = (T*)p.y + ((size_t)stat * p.rows_per_stat) * p.ldy + cc * 8;
+  auto one = [&](int r, const vec<T, 8>& v) {
     vec<T, 8> o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -131,21 +139,17 @@ STAR_GLOBAL void gn_apply_kernel(const GnApplyParams p) {
       if (p.silu) f = silu_f(f);
       o[e] = from_f32<T>(f);
     }
-    *reinterpret_cast<vec<T, 8>*>((T*)p.y + (size_t)row * p.ldy + cc * 8) = o;
+    *reinterpret_cast<vec<T, 8>*>(yb + (size_t)r * p.ldy) = o;
   };
-  auto src = [&](long long q) {
-    const int row = (int)(q / CC8), cc = (int)(q - (long long)row * CC8);
-    return reinterpret_cast<const vec<T, 8>*>((const T*)p.x + (size_t)row * p.ldx + cc * 8);
-  };
-  long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  for (; q + 3 * stride < total; q += 4 * stride) {   // four independent 16-B loads in flight per lane
+  int r = r0 + rl;
+  for (; r + 3 * RL < r1; r += 4 * RL) {   // four independent 16-B loads in flight per lane
     vec<T, 8> v[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) v[u] = *src(q + u * stride);
+    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const vec<T, 8>*>(xb + (size_t)(r + u * RL) * p.ldx);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) one(q + u * stride, v[u]);
+    for (int u = 0; u < 4; ++u) one(r + u * RL, v[u]);
   }
-  for (; q < total; q += stride) one(q, *src(q));
+  for (; r < r1; r += RL) one(r, *reinterpret_cast<const vec<T, 8>*>(xb + (size_t)r * p.ldx));
 }
 
 // ------------------------------------------------------------------ LayerNorm rows (+ LIEM gates)
