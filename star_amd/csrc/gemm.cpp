@@ -59,6 +59,7 @@ static int launch_gemm(Ctx* ctx, const GemmArgs& a) {
     case 8: return launch_gemm_t<T, 256, 320, 4, 2, 2, false, 4>(ctx, a);
     // two independent 4-wave workgroups per CU (72 / 56 KB of LDS each): one group's epilogue and DMA latency hide
     // behind the other group's MFMA burst
+    case 14: return launch_gemm_t<T, 256, 256, 2, 2, 1>(ctx, a);   // 4 waves x (128 x 128), one wave per SIMD, accumulators in AGPRs: 1/3 fewer LDS fragment reads
     case 9: return launch_gemm_t<T, 128, 256, 2, 2, 2, false, 3>(ctx, a);
     case 10: return launch_gemm_t<T, 128, 320, 2, 2, 2, false, 2>(ctx, a);
   }

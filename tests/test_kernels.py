@@ -44,7 +44,7 @@ GEMM_CASES = [  # M, N, K, tile
     (300, 192, 128, 3), (256, 256, 64, 1), (515, 320, 128, 2), (260, 128, 64, 4), (100, 72, 64, 0),
     (77, 1280, 1024, 0), (1, 64, 64, 0), (600, 960, 320, 0), (513, 640, 192, 0), (515, 512, 256, 5), (700, 1024, 64, 5),
     (515, 512, 256, 7), (700, 640, 192, 8), (300, 320, 64, 8), (257, 256, 192, 7), (600, 960, 64, 8),
-    (515, 512, 256, 9), (130, 256, 64, 9), (700, 640, 192, 10), (300, 320, 64, 10), (257, 960, 128, 10), (400, 264, 320, 9),
+    (515, 512, 256, 9), (130, 256, 64, 9), (700, 640, 192, 10), (300, 320, 64, 10), (257, 960, 128, 10), (400, 264, 320, 9), (515, 512, 256, 14), (300, 264, 64, 14),
 ]
 
 
