@@ -63,7 +63,7 @@ static int launch_gemm(Ctx* ctx, const GemmArgs& a) {
     case 9: return launch_gemm_t<T, 128, 256, 2, 2, 2, false, 3>(ctx, a);
     case 10: return launch_gemm_t<T, 128, 320, 2, 2, 2, false, 2>(ctx, a);
   }
-  if (tile >= 11 && tile <= 13 && a.mode == A_PLAIN && !(a.epi & EPI_OUT_F32)) {   // ablation probes of the 256x256 main loop
+  if (tile >= 11 && tile <= 16 && tile != 14 && a.mode == A_PLAIN && !(a.epi & EPI_OUT_F32)) {   // ablation probes of the 256x256 main loop
     GemmParams p{};
     p.A = a.A; p.W = a.W; p.C = a.C; p.bias = a.bias; p.res = a.res; p.zero_page = ctx->zero_page;
     p.M = a.M; p.N = a.N; p.K = a.K; p.lda = a.lda; p.ldc = a.ldc; p.ldr = a.ldr; p.epi = a.epi;
@@ -73,6 +73,8 @@ static int launch_gemm(Ctx* ctx, const GemmArgs& a) {
     if (tile == 11) STAR_LAUNCH((gemm_kernel<T, 256, 256, 4, 2, A_PLAIN, 2, false, false, 1>), grid, block, smem, ctx->stream, p);
     if (tile == 12) STAR_LAUNCH((gemm_kernel<T, 256, 256, 4, 2, A_PLAIN, 2, false, false, 2>), grid, block, smem, ctx->stream, p);
     if (tile == 13) STAR_LAUNCH((gemm_kernel<T, 256, 256, 4, 2, A_PLAIN, 2, false, false, 3>), grid, block, smem, ctx->stream, p);
+    if (tile == 15) STAR_LAUNCH((gemm_kernel<T, 256, 256, 4, 2, A_PLAIN, 2, false, false, 4>), grid, block, smem, ctx->stream, p);   // no K loop at all
+    if (tile == 16) STAR_LAUNCH((gemm_kernel<T, 256, 256, 4, 2, A_PLAIN, 2, false, false, 5>), grid, block, smem, ctx->stream, p);   // no global stores
     return 0;
   }
   return ctx->fail("gemm: bad tile id");

@@ -321,8 +321,8 @@ gemm_kernel(const GemmParams p) {
 #pragma unroll
       for (int j = 0; j < TN; ++j) acc[i][j] = mfma32<T>(w[j], a[i], acc[i][j]);
   };
-  stage(0, 0);
-  for (int kt = 0; kt < nk; ++kt) {
+  if constexpr (ABL != 4) stage(0, 0);
+  for (int kt = 0; kt < (ABL == 4 ? 0 : nk); ++kt) {
     glds_wait();
     block_sync();
     if (kt + 1 < nk && (ABL != 3 || kt == 0)) stage(kt + 1, (kt + 1) & 1);
@@ -439,7 +439,7 @@ gemm_kernel(const GemmParams p) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) ov[e] = from_f32<T>(to_f32<T>(ov[e]) + to_f32<T>(rv[i][u][e]));
           }
-          *reinterpret_cast<vec<T, 8>*>((T*)p.C + (size_t)m * p.ldc + n) = ov;
+          if (ABL != 5 || p.M < 0) *reinterpret_cast<vec<T, 8>*>((T*)p.C + (size_t)m * p.ldc + n) = ov;
         }
       }
     };

@@ -11,7 +11,8 @@ b = torch.randn(N, device="cuda")
 out = torch.empty(M, N, device="cuda", dtype=dt)
 outg = torch.empty(M, N // 2, device="cuda", dtype=dt)
 names = {1: "full kernel", 11: "no LDS fragment reads (constant frags)", 12: "no MFMA (reads kept live)",
-         13: "no re-staging after tile 0 (no LDS-DMA in the loop)", -1: "full kernel, GEGLU epilogue (half the output)"}
+         13: "no re-staging after tile 0 (no LDS-DMA in the loop)", 15: "no K loop at all (launch + epilogue only)",
+         16: "no global stores (everything else kept)", -1: "full kernel, GEGLU epilogue (half the output)"}
 def run(tile):
     if tile == -1:
         ctx.gemm(A, W, bias=b, out=outg, geglu=True, force_tile=1)
