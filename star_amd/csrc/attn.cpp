@@ -36,10 +36,14 @@ static int launch_flash(Ctx* ctx, const AttnArgs& a) {
   else if (a.variant == 7) STAR_LAUNCH((flash_attn_v3_kernel<T, 2, 2>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);
   else if (a.variant == 8) STAR_LAUNCH((flash_attn_v3_kernel<T, 2, 3>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);
   else if (a.variant == 9) STAR_LAUNCH((flash_attn_v3_kernel<T, 2, 1, 0, 1>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);
+  else if (a.variant == 10) STAR_LAUNCH((flash_attn_v3_kernel<T, 2, 4>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);
+  else if (a.variant == 15) STAR_LAUNCH((flash_attn_v3_kernel<T, 2, 5>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);
   else if (a.variant == 11) STAR_LAUNCH((flash_attn_v3_kernel<T, 2, 1, 1>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);   // ablation probes of variant 6:
   else if (a.variant == 12) STAR_LAUNCH((flash_attn_v3_kernel<T, 2, 1, 2>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);   // no exp / no PV MFMA /
   else if (a.variant == 13) STAR_LAUNCH((flash_attn_v3_kernel<T, 2, 1, 3>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);   // no K/V staging /
   else if (a.variant == 14) STAR_LAUNCH((flash_attn_v3_kernel<T, 2, 1, 4>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);   // no staging, no barriers
+  else if (a.variant == 16) STAR_LAUNCH((flash_attn_v3_kernel<T, 2, 1, 5, 1>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);   // no softmax VALU
+  else if (a.variant == 17) STAR_LAUNCH((flash_attn_v3_kernel<T, 2, 1, 3, 1>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);   // variant 9 without staging
   else if (a.variant == 4) {   // software-pipelined, 128-row workgroups
     p.nqb = (a.Nq + 127) / 128;
     const long long nblk4 = 8LL * p.nqb * ((BH + 7) / 8);

@@ -605,7 +605,11 @@ flash_attn_v3_kernel(const AttnParams p) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           vec<T, 8> pk;
-          if constexpr (ROWSUM == 1) {
+          if constexpr (ABL == 5) {      // no softmax VALU at all: constant probabilities (keeps the MFMA / LDS / barrier skeleton)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pk[e] = from_f32<T>(0.001f);
+            ls0 += s[qi][kb][8 * u];     // one VALU per 8 scores keeps the QK MFMAs alive
+          } else if constexpr (ROWSUM == 1) {
             float e8[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) e8[e] = fast_exp2(s[qi][kb][8 * u + e]);
@@ -680,6 +684,117 @@ flash_attn_v3_kernel(const AttnParams p) {
 #pragma unroll
       for (int qi = 0; qi < NQ; ++qi) l_run[qi] += lsum[qi];
       pv(0, NQ);
+    } else if constexpr (LAZY == 4 || LAZY == 5) {
+      // chunk pipeline (variants 10 / 11): the tile is four chunks (query block qi, key half kb) of 5 MFMAs and ~40 VALU
+      // each; the exponentials of one chunk are issued in the MFMA gaps of the next.  Measured on gfx950
+      // (tools/probe/overlap.hip): a VALU instruction costs ~8 cycles in a VALU-only stretch of a wave but ~1.3 when up to
+      // six of them follow each 32-cycle MFMA.  K fragments of a key half serve both query blocks back to back, V
+      // fragments likewise, so LDS traffic is unchanged.  LAZY == 5 adds sched_group_barrier patterns.
+      static_assert(NQ == 2, "chunk pipeline is written for two query blocks per wave");
+      constexpr bool HINTS = (LAZY == 5);
+      vec<T, 8> kfr[4];
+      auto load_k = [&](int kb) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) kfr[ks] = *reinterpret_cast<const vec<T, 8>*>(kbuf + swz_off(kb * 32 + lq, ks * 2 + h2));
+      };
+      auto qk = [&](int qi, int kb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[qi][kb][r] = 0.f;
+        s[qi][kb] = mfma32<T>(kaug, qaug[qi], s[qi][kb]);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) s[qi][kb] = mfma32<T>(kfr[ks], qf[qi][ks], s[qi][kb]);
+        if constexpr (MASK) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = t * KT + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
+            if (key >= p.Nk) s[qi][kb][r] = -1e30f;
+          }
+        }
+      };
+      float lk[NQ];
+      auto expo_c = [&](int qi, int kb) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          float e8[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) e8[e] = fast_exp2(s[qi][kb][8 * u + e]);
+#pragma unroll
+          for (int e = 0; e < 8; e += 4) { a0 += e8[e]; a1 += e8[e + 1]; a2 += e8[e + 2]; a3 += e8[e + 3]; }
+          vec<T, 8> pk;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) pk[e] = from_f32<T>(e8[e]);
+          pf[qi][kb * 2 + u] = pk;
+        }
+        lk[qi] += (a0 + a1) + (a2 + a3);
+      };
+      vec<T, 8> vfr[2][2];
+      auto load_v = [&](int kb) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int db = 0; db < 2; ++db) vfr[u][db] = load_vt_frag<T>(vbuf, (kb * 2 + u) * 16, db, lane);
+      };
+      auto pv_c = [&](int qi, int kb) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int db = 0; db < 2; ++db) oacc[qi][db] = mfma32<T>(vfr[u][db], pf[qi][kb * 2 + u], oacc[qi][db]);
+      };
+      auto fix = [&](int qi) {   // rare: exact maxima from recomputed scores, move the running max, redo this block's P
+        load_k(0); qk(qi, 0);
+        load_k(1); qk(qi, 1);
+        maxima(qi, qi + 1);
+        rebase(qi, qi + 1);
+        lk[qi] = 0.f;
+        expo_c(qi, 0);
+        expo_c(qi, 1);
+      };
+      auto hints = [&](auto n_ds, auto n_mfma, auto n_valu) {   // integral_constant arguments: the builtin wants literals
+#ifndef STAR_HOSTEMU
+        if constexpr (HINTS) {
+          if constexpr (decltype(n_ds)::value > 0) STAR_SCHED_GROUP(0x100, decltype(n_ds)::value, 0);
+#pragma unroll
+          for (int i = 0; i < decltype(n_mfma)::value; ++i) {
+            STAR_SCHED_GROUP(0x008, 1, 0);
+            STAR_SCHED_GROUP(0x002, decltype(n_valu)::value, 0);
+          }
+        }
+#endif
+      };
+      if constexpr (FIRST) {              // the first tile sets the running max from exact maxima
+        scores(0, NQ);
+        maxima(0, NQ);
+        rebase(0, NQ);
+#pragma unroll
+        for (int qi = 0; qi < NQ; ++qi) { expo(qi); l_run[qi] += lsum[qi]; }
+        pv(0, NQ);
+      } else {
+        lk[0] = 0.f; lk[1] = 0.f;
+        load_k(0);
+        qk(0, 0);                                   // R0
+        STAR_SCHED_FENCE();
+        qk(1, 0); expo_c(0, 0);                     // R1: QK(q1,k0) beside exp(q0,k0)
+        hints(std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{}, std::integral_constant<int, 8>{});
+        STAR_SCHED_FENCE();
+        load_k(1);
+        qk(0, 1); expo_c(1, 0);                     // R2: QK(q0,k1) beside exp(q1,k0)
+        hints(std::integral_constant<int, 4>{}, std::integral_constant<int, 5>{}, std::integral_constant<int, 8>{});
+        STAR_SCHED_FENCE();
+        qk(1, 1); expo_c(0, 1);                     // R3: QK(q1,k1) beside exp(q0,k1)
+        hints(std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{}, std::integral_constant<int, 8>{});
+        if (wave_any(!(lk[0] <= LAZY_BIG))) fix(0);
+        l_run[0] += lk[0];
+        load_v(0);
+        pv_c(0, 0); expo_c(1, 1);                   // R4: PV(q0,k0) beside exp(q1,k1)
+        hints(std::integral_constant<int, 8>{}, std::integral_constant<int, 4>{}, std::integral_constant<int, 10>{});
+        if (wave_any(!(lk[1] <= LAZY_BIG))) fix(1);
+        l_run[1] += lk[1];
+        pv_c(1, 0);                                 // R5: the rest of PV
+        load_v(1);
+        pv_c(0, 1);
+        pv_c(1, 1);
+      }
     } else if constexpr (LAZY == 3) {
       // key-half pipeline: the tile is processed as two 32-key halves; the exponentials of one half run beside the
       // MFMAs of the other (QK of half 1 beside exp of half 0, PV of half 0 beside exp of half 1).  K / V fragments are
@@ -822,7 +937,7 @@ flash_attn_v3_kernel(const AttnParams p) {
   stage(0, 0);
   const bool has_tail = (p.Nk & (KT - 1)) != 0;
   const int nfull = has_tail ? nt - 1 : nt;
-  if constexpr (LAZY == 3) {
+  if constexpr (LAZY >= 3) {
     if (nfull > 0) {
       glds_wait(); block_sync();
       if (1 < nt) stage(1, 1);

@@ -11,7 +11,7 @@ C = heads * 64
 qkv = torch.randn(B, N, 3 * C, device=dev, dtype=torch.float16)
 out = torch.empty(B, N, C, device=dev, dtype=torch.float16)
 flops = 4.0 * B * heads * N * N * 64
-names = {6: "full kernel (variant 6)", 11: "exp2 -> one v_mul", 12: "no PV MFMAs", 13: "no K/V staging after tile 1", 14: "no staging, no barriers"}
+names = {9: "full kernel (variant 9)", 16: "variant 9, no softmax VALU (constant P)", 17: "variant 9, no K/V staging after tile 1", 6: "full kernel (variant 6)", 11: "exp2 -> one v_mul", 12: "no PV MFMAs", 13: "no K/V staging after tile 1", 14: "no staging, no barriers"}
 def t_ms(v, iters=3):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
