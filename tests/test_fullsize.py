@@ -1,0 +1,55 @@
+"""BASELINE config[1] sizes (32 frames, latent 122 x 216, the full 2.04 B-parameter architecture) on hardware: properties that
+do not need a CPU oracle (the fp32 CPU path would take hours at this size)."""
+import math
+
+import pytest
+import torch
+
+
+@pytest.mark.gpu
+def test_spatial_attention_full_length_vs_fp32():
+    """one (frame, head) of the L0 spatial self-attention at its real length N = 26352 against fp32 softmax(QK^T/8)V."""
+    from util import make_ctx
+    ctx = make_ctx("hip", torch.float16, None)
+    dev = ctx.torch_device
+    g = torch.Generator().manual_seed(3)
+    N = 122 * 216
+    qkv = (torch.randn(2, N, 192, generator=g) * 1.5).to(torch.float16).to(dev)      # 2 frames, 1 head, fused QKV rows
+    out = ctx.attention(qkv[..., :64], qkv[..., 64:128], qkv[..., 128:], 1).float()
+    q, k, v = (qkv[..., i * 64:(i + 1) * 64].float() for i in range(3))
+    ref = torch.empty_like(out)
+    for b in range(2):
+        for s in range(0, N, 4096):                                                  # 4096 x 26352 fp32 logits at a time
+            p = torch.softmax(q[b, s:s + 4096] @ k[b].T / 8.0, dim=-1)
+            ref[b, s:s + 4096] = p @ v[b]
+    err = float((out - ref).abs().max())
+    assert err <= 4e-3 * max(1.0, float(ref.abs().max())), err
+    ctx.sync()
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_full_model_forward_pair_at_cfg2_size():
+    """the whole denoiser at cfg2 size: finite, the shared-prefix CFG pair is bit-identical to two plain forwards, and the
+    two text contexts give different predictions."""
+    from star_amd.modules.unet_v2v import ControlledV2VUNet
+    from star_amd.topology import UNetConfig, random_state_dict
+    cfg = UNetConfig()
+    net = ControlledV2VUNet(cfg, dtype=torch.float16, device=0)
+    net.load_state_dict(random_state_dict(cfg, seed=0))
+    net.release_host_weights()
+    g = torch.Generator().manual_seed(1)
+    f, h, w = 32, 122, 216
+    x = torch.randn(1, 4, f, h, w, generator=g).cuda()
+    hint = (torch.randn(1, 4, f, h, w, generator=g) * 0.5).cuda()
+    y = torch.randn(1, 77, 1024, generator=g).cuda()
+    y2 = torch.randn(1, 77, 1024, generator=g).cuda()
+    t = torch.tensor([500])
+    a = net(x, t=t, y=y, hint=hint)
+    pa, pb = net.forward_cfg_pair(x, t, y, y2, hint=hint)
+    assert a.shape == x.shape and torch.isfinite(pa).all() and torch.isfinite(pb).all()
+    assert torch.equal(a, pa)
+    b = net(x, t=t, y=y2, hint=hint)
+    assert torch.equal(b, pb)
+    assert float((pa - pb).abs().mean()) > 0
+    assert 1e-3 < float(pa.std()) < 1e3 and not math.isnan(float(pa.mean()))
