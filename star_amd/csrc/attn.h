@@ -1228,6 +1228,298 @@ flash_attn_v4_kernel(const AttnParams p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// flash_attn_v6_kernel (variant 20): the two waves of a SIMD in enforced antiphase.  Measured on gfx950
+// (tools/probe/overlap.hip): a wave alone in a VALU-only stretch issues one VALU per ~8 cycles and the matrix pipe idles;
+// left to themselves the two workgroups of a CU drift, and the softmax VALU (39 % of the tile time) never hides.  Here a
+// 512-thread workgroup owns 512 query rows; waves 0-3 and waves 4-7 (the two waves of each SIMD) run the same per-tile
+// program half a period apart, separated by one workgroup barrier per half-step:
+//     MFMA phase(t) = PV(t-1) then QK(t)          |  VALU phase(t) = softmax of tile t (lazy maxima, as variant 9)
+// so one wave of every SIMD is always in its MFMA phase while its partner is in its VALU phase.  K tiles live in a ring of
+// three (the lagging group may have to recompute scores of tile t one half-step after tile t+2 started loading), V tiles
+// in a ring of two; all eight waves share the LDS-DMA of K(t+1) and V(t) at the even half-steps.
+template <class T>
+STAR_GLOBAL void STAR_LAUNCH_BOUNDS(512, 2)
+flash_attn_v6_kernel(const AttnParams p) {
+  constexpr int NQ = 2, QW = 64, QB = 8 * QW, KT = 64, TILE = KT * 128;
+  constexpr float LAZY_BIG = 1024.0f;
+  char* smem = dyn_smem();                     // [3] K tiles | [2] V tiles
+  char* kring = smem;
+  char* vring = smem + 3 * TILE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = wave_uniform(wave >> 2);
+  const int h2 = lane >> 5, lq = lane & 31;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int bh = xcd + 8 * (slot / p.nqb);
+  const int qb = slot % p.nqb;
+  if (bh >= p.batch * p.heads) return;
+  const int b = bh / p.heads, hd = bh % p.heads;
+  const T* __restrict__ Qg = (const T*)p.Q + (size_t)b * p.bsq + hd * 64;
+  const T* __restrict__ Kg = (const T*)p.K + (size_t)b * p.bsk + hd * 64;
+  const T* __restrict__ Vg = (const T*)p.V + (size_t)b * p.bsv + hd * 64;
+  T* __restrict__ Og = (T*)p.O + (size_t)b * p.bso + hd * 64;
+
+  vec<T, 8> qf[NQ][4];
+  const int q_base = qb * QB + wave * QW;
+#pragma unroll
+  for (int qi = 0; qi < NQ; ++qi) {
+    int q = q_base + qi * 32 + lq;
+    if (q > p.Nq - 1) q = p.Nq - 1;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const vec<T, 8> raw = *reinterpret_cast<const vec<T, 8>*>(Qg + (size_t)q * p.ldq + ks * 16 + h2 * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qf[qi][ks][e] = from_f32<T>(to_f32<T>(raw[e]) * p.scale_log2e);
+    }
+  }
+  vec<T, 8> kaug, qaug[NQ];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    kaug[e] = from_f32<T>(0.f);
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) qaug[qi][e] = from_f32<T>(0.f);
+  }
+  if (h2 == 0) kaug[0] = from_f32<T>(1.0f);
+
+  // one 16-B chunk per thread per tile: chunk q = tid -> row q >> 3, stored position q & 7 holds source chunk pos ^ swizzle
+  const int srow = tid >> 3, spos = tid & 7, schunk = spos ^ ((srow >> 1) & 7);
+  auto stage_k = [&](int t, int slot_) STAR_ALWAYS_INLINE {
+    int key = t * KT + srow;
+    if (key > p.Nk - 1) key = p.Nk - 1;
+    glds16(Kg + (size_t)key * p.ldk + schunk * 8, kring + slot_ * TILE + (size_t)(wave * 64) * 16);
+  };
+  auto stage_v = [&](int t, int slot_) STAR_ALWAYS_INLINE {
+    int key = t * KT + srow;
+    if (key > p.Nk - 1) key = p.Nk - 1;
+    glds16(Vg + (size_t)key * p.ldv + schunk * 8, vring + slot_ * TILE + (size_t)(wave * 64) * 16);
+  };
+
+  f32x16 oacc[NQ][2];
+#pragma unroll
+  for (int a = 0; a < NQ; ++a)
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[a][c2][r] = 0.f;
+  float m_run[NQ] = {0.f, 0.f}, l_run[NQ] = {0.f, 0.f};
+  const int T_ = (p.Nk + KT - 1) / KT;
+  const bool has_tail = (p.Nk & (KT - 1)) != 0;
+
+  f32x16 s[NQ][2];
+  vec<T, 8> pf[NQ][4];
+  float lsum[NQ], m_tile[NQ];
+
+  auto scores = [&](int t, const char* kbuf) STAR_ALWAYS_INLINE {
+#pragma unroll
+    for (int a = 0; a < NQ; ++a)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[a][kb][r] = 0.f;
+        s[a][kb] = mfma32<T>(kaug, qaug[a], s[a][kb]);
+      }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        const vec<T, 8> kf = *reinterpret_cast<const vec<T, 8>*>(kbuf + swz_off(kb * 32 + lq, ks * 2 + h2));
+#pragma unroll
+        for (int qi = 0; qi < NQ; ++qi) s[qi][kb] = mfma32<T>(kf, qf[qi][ks], s[qi][kb]);
+      }
+    if (has_tail && t == T_ - 1) {             // key tail of the last tile
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = t * KT + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
+          if (key >= p.Nk) {
+#pragma unroll
+            for (int qi = 0; qi < NQ; ++qi) s[qi][kb][r] = -1e30f;
+          }
+        }
+    }
+  };
+  auto maxima = [&]() STAR_ALWAYS_INLINE {
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) {
+      float mx[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int kb = g >> 1, o = (g & 1) * 8;
+        const float a0 = fmaxf(fmaxf(s[qi][kb][o], s[qi][kb][o + 1]), s[qi][kb][o + 2]);
+        const float a1 = fmaxf(fmaxf(s[qi][kb][o + 3], s[qi][kb][o + 4]), s[qi][kb][o + 5]);
+        mx[g] = fmaxf(fmaxf(a0, a1), fmaxf(s[qi][kb][o + 6], s[qi][kb][o + 7]));
+      }
+      m_tile[qi] = pair_max(fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3])));
+    }
+  };
+  auto rebase = [&](bool first) STAR_ALWAYS_INLINE {
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) {
+      const float inc = first ? m_tile[qi] : fmaxf(m_tile[qi], 0.f);
+      const float m_new = to_f32<T>(from_f32<T>(m_run[qi] + inc));
+      const float delta = m_new - m_run[qi];
+      const float alpha = fast_exp2(-delta);
+      m_run[qi] = m_new;
+      l_run[qi] *= alpha;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[qi][db][r] *= alpha;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[qi][kb][r] -= delta;
+      if (h2 == 0) qaug[qi][0] = from_f32<T>(-m_new);
+    }
+  };
+  auto expo = [&]() STAR_ALWAYS_INLINE {
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) {
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          float e8[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) e8[e] = fast_exp2(s[qi][kb][8 * u + e]);
+#pragma unroll
+          for (int e = 0; e < 8; e += 4) { a0 += e8[e]; a1 += e8[e + 1]; a2 += e8[e + 2]; a3 += e8[e + 3]; }
+          vec<T, 8> pk;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) pk[e] = from_f32<T>(e8[e]);
+          pf[qi][kb * 2 + u] = pk;
+        }
+      lsum[qi] = (a0 + a1) + (a2 + a3);
+    }
+  };
+  auto pv = [&](const char* vbuf) STAR_ALWAYS_INLINE {
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        const vec<T, 8> vf = load_vt_frag<T>(vbuf, tt * 16, db, lane);
+#pragma unroll
+        for (int qi = 0; qi < NQ; ++qi) oacc[qi][db] = mfma32<T>(vf, pf[qi][tt], oacc[qi][db]);
+      }
+  };
+
+  // ---- prologue: K(0)
+  stage_k(0, 0);
+  glds_wait();
+  block_sync();
+  // half-steps 2t (even: the DMA of K(t+1), V(t) starts) and 2t+1 (odd: it must have landed before the next half-step);
+  // group 0 runs MFMA(t) | VALU(t), group 1 runs VALU(t-1) | MFMA(t): two straight-line loops, one per group, so that the
+  // scores / probabilities are never live together across the loop edge
+  auto start_dma = [&](int t) STAR_ALWAYS_INLINE {
+    if (t + 1 < T_) stage_k(t + 1, (t + 1) % 3);
+    if (t < T_) stage_v(t, t & 1);
+  };
+  auto softmax_first = [&]() STAR_ALWAYS_INLINE {            // tile 0 sets the running max from exact maxima
+    maxima();
+    rebase(true);
+    expo();
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) l_run[qi] += lsum[qi];
+  };
+  auto softmax_lazy = [&](int t) STAR_ALWAYS_INLINE {         // tile t >= 1: no maxima unless the row-sum probe fails
+    expo();
+    bool bad = false;
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) bad = bad || !(lsum[qi] <= LAZY_BIG);
+    if (wave_any(bad)) {                         // rare: exact maxima from recomputed scores (K(t) is still in its ring slot)
+      scores(t, kring + (t % 3) * TILE);
+      maxima();
+      rebase(false);
+      expo();
+    }
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) l_run[qi] += lsum[qi];
+  };
+  // first and last tiles are peeled so that the steady-state loops carry no tile-index branches
+  if (grp == 0) {                                // MFMA(t) | VALU(t)
+    start_dma(0);
+    scores(0, kring);
+    barrier_keep_dma();
+    softmax_first();
+    glds_wait();
+    barrier_keep_dma();
+    for (int t = 1; t < T_; ++t) {
+      start_dma(t);
+      pv(vring + ((t - 1) & 1) * TILE);
+      scores(t, kring + (t % 3) * TILE);
+      barrier_keep_dma();
+      softmax_lazy(t);
+      glds_wait();
+      barrier_keep_dma();
+    }
+    pv(vring + ((T_ - 1) & 1) * TILE);
+    barrier_keep_dma();
+    barrier_keep_dma();
+  } else {                                       // VALU(t-1) | MFMA(t)
+    start_dma(0);
+    barrier_keep_dma();
+    scores(0, kring);
+    glds_wait();
+    barrier_keep_dma();
+    if (T_ > 1) {
+      start_dma(1);
+      softmax_first();
+      barrier_keep_dma();
+      pv(vring);
+      scores(1, kring + TILE);
+      glds_wait();
+      barrier_keep_dma();
+      for (int t = 2; t < T_; ++t) {
+        start_dma(t);
+        softmax_lazy(t - 1);
+        barrier_keep_dma();
+        pv(vring + ((t - 1) & 1) * TILE);
+        scores(t, kring + (t % 3) * TILE);
+        glds_wait();
+        barrier_keep_dma();
+      }
+      softmax_lazy(T_ - 1);
+      barrier_keep_dma();
+      pv(vring + ((T_ - 1) & 1) * TILE);
+      barrier_keep_dma();
+    } else {
+      softmax_first();
+      barrier_keep_dma();
+      pv(vring);
+      barrier_keep_dma();
+    }
+  }
+
+#pragma unroll
+  for (int qi = 0; qi < NQ; ++qi) {
+    const float l = pair_sum(l_run[qi]);
+    const float inv = 1.0f / l;
+    const int q = q_base + qi * 32 + lq;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        uint32_t w0[2], w1[2];
+#pragma unroll
+        for (int gg = 0; gg < 2; ++gg) {
+          vec<T, 4> o4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o4[e] = from_f32<T>(oacc[qi][db][(2 * a + gg) * 4 + e] * inv);
+          u32x2 pk = __builtin_bit_cast(u32x2, o4);
+          if (gg == 0) { w0[0] = pk[0]; w0[1] = pk[1]; } else { w1[0] = pk[0]; w1[1] = pk[1]; }
+        }
+        const u32x2 x0 = permlane32_swap(w0[0], w1[0]);
+        const u32x2 x1 = permlane32_swap(w0[1], w1[1]);
+        u32x4 out;
+        out[0] = x0[0]; out[1] = x1[0]; out[2] = x0[1]; out[3] = x1[1];
+        if (q < p.Nq) *reinterpret_cast<u32x4*>(Og + (size_t)q * p.ldo + 32 * db + 16 * a + 8 * h2) = out;
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 struct TAttnParams {
   const void* Q; const void* K; const void* V; void* O;
   int ldq, ldk, ldv, ldo;   // row strides (elements) of the [F*HW, *] token matrices

@@ -27,6 +27,9 @@ typedef void* hipStream_t;
 #define STAR_LAUNCH_BOUNDS(...) __launch_bounds__(__VA_ARGS__)
 #endif
 
+// lambdas that are expanded at several call sites of one kernel: never outline them (a call spills the live accumulators)
+#define STAR_ALWAYS_INLINE __attribute__((always_inline))
+
 namespace star {
 
 using f16 = _Float16;
