@@ -65,6 +65,14 @@ __global__ void __launch_bounds__(512) k_overlap(long long* out, int iters, int 
       if (valu_role) BODY(EXP6 EXP6 EXP6 EXP6); else BODY(MF MG MF MG);
     }
     if (MODE == 13) BODY(MF MG MF MG FMA8 FMA8 FMA8 FMA8);             // same work as mode 4, phases not interleaved
+    if (MODE == 14) {                                                  // cross-wave with the MFMA wave at raised priority
+      if (valu_role) BODY(FMA8 FMA8 FMA8 FMA8); else BODY("s_setprio 3\n" MF MG MF MG);
+    }
+    if (MODE == 15) BODY(MF MG MF MG MF MG MF MG MF MG MF MG MF MG MF MG FMA8 FMA8 FMA8 FMA8 FMA8 FMA8 FMA8 FMA8);   // 16 MFMA then 64 fma
+    if (MODE == 16) BODY(MF MG MF MG MF MG MF MG MF MG MF MG MF MG MF MG EXP6 FMA8 EXP6 FMA8 EXP6 FMA8 EXP6 FMA8 FMA8);  // 16 MFMA then 24 exp + 40 fma
+    if (MODE == 17) {                                                  // phase streams with priority raised for the MFMA burst only
+      BODY("s_setprio 3\n" MF MG MF MG MF MG MF MG MF MG MF MG MF MG MF MG "s_setprio 0\n" FMA8 FMA8 FMA8 FMA8 FMA8 FMA8 FMA8 FMA8);
+    }
   }
   const long long t1 = __builtin_readcyclecounter();
   float sink = f[0] + f[1] + f[2] + f[3] + f[4] + f[5] + f[6] + f[7] + acc0[0] + acc1[0];
@@ -84,7 +92,7 @@ static void run(const char* name, int threads, int role_split) {
   CK(hipMemcpy(h.data(), d, 8 * sizeof(long long), hipMemcpyDeviceToHost));
   const int nw = threads / 64;
   printf("%-58s", name);
-  for (int w = 0; w < nw; w += (nw > 4 ? 4 : 1)) printf("  wave%d %7.1f", w, (double)h[w] / iters);
+  for (int w = 0; w < nw; w += (nw > 4 ? 4 : 3)) printf("  wave%d %7.1f", w, (double)h[w] / iters);
   printf("   (s_memtime ticks per iteration; 4 MFMAs = 128 matrix-pipe cycles)\n");
   CK(hipFree(d));
 }
@@ -113,5 +121,12 @@ int main() {
   printf("---- two waves per SIMD: waves 0-3 MFMA-only, waves 4-7 VALU-only\n");
   run<11>("4 MFMA | 32 fma", 512, 1);
   run<12>("4 MFMA | 24 exp", 512, 1);
+  run<14>("4 MFMA at s_setprio 3 | 32 fma", 512, 1);
+  printf("---- attention-like phase streams: 16 MFMA (512 pipe cycles) then 64 VALU, every wave the same program\n");
+  run<15>("1 wave/SIMD : 16 MFMA then 64 fma", 256, 0);
+  run<15>("2 waves/SIMD: 16 MFMA then 64 fma", 512, 0);
+  run<16>("1 wave/SIMD : 16 MFMA then 24 exp + 40 fma", 256, 0);
+  run<16>("2 waves/SIMD: 16 MFMA then 24 exp + 40 fma", 512, 0);
+  run<17>("2 waves/SIMD: 16 MFMA (prio 3) then 64 fma (prio 0)", 512, 0);
   return 0;
 }
