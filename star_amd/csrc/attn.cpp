@@ -44,6 +44,8 @@ static int launch_flash(Ctx* ctx, const AttnArgs& a) {
   else if (a.variant == 14) STAR_LAUNCH((flash_attn_v3_kernel<T, 2, 1, 4>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);   // no staging, no barriers
   else if (a.variant == 16) STAR_LAUNCH((flash_attn_v3_kernel<T, 2, 1, 5, 1>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);   // no softmax VALU
   else if (a.variant == 17) STAR_LAUNCH((flash_attn_v3_kernel<T, 2, 1, 3, 1>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);   // variant 9 without staging
+  else if (a.variant == 21) STAR_LAUNCH((flash_attn_v3_kernel<T, 2, 1, 0, 1, 1>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);
+  else if (a.variant == 22) STAR_LAUNCH((flash_attn_v3_kernel<T, 2, 1, 0, 1, 0, 1>), dim3((unsigned)nblk), dim3(256), (size_t)(3 * 16384), ctx->stream, p);
   else if (a.variant == 20) {   // enforced antiphase, 512-row workgroups
     p.nqb = (a.Nq + 511) / 512;
     const long long nblk5 = 8LL * p.nqb * ((BH + 7) / 8);

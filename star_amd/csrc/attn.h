@@ -441,7 +441,11 @@ flash_attn_v2_kernel(const AttnParams p) {
 // ROWSUM = 1: row sums as four chains of plain fp32 adds on the unrounded exponentials instead of v_dot2c on the packed P
 // (v_dot2c costs ~10 cycles beyond its issue slot beside MFMAs; attn.o is built with -fno-slp-vectorize so the adds stay
 // single-issue instead of being fused into v_pk_add_f32, which stalls beside MFMAs as well).
-template <class T, int NQ, int LAZY = 0, int ABL = 0, int ROWSUM = 0>   // NQ = 32-row query blocks per wave: 2 -> 2 waves/SIMD (256 VGPRs), 1 -> 4 waves/SIMD (128 VGPRs); ABL: ablation probes (bench only)
+// KPRE = 1 (variant 21): all eight K fragments of a tile are read before its first MFMA (the probabilities of the previous
+// tile are dead by then, so their 32 registers are free) instead of two at a time just ahead of their use.
+// RING3 = 1 (variant 22): K/V tiles in a ring of three, the LDS-DMA of tile t+2 is issued at tile t and waited with a counted
+// vmcnt behind a raw s_barrier, so a tile never waits for a DMA issued only one tile earlier.
+template <class T, int NQ, int LAZY = 0, int ABL = 0, int ROWSUM = 0, int KPRE = 0, int RING3 = 0>   // NQ = 32-row query blocks per wave: 2 -> 2 waves/SIMD (256 VGPRs), 1 -> 4 waves/SIMD (128 VGPRs); ABL: ablation probes (bench only)
 STAR_GLOBAL void STAR_LAUNCH_BOUNDS(256, (NQ == 2 ? 2 : 4))
 flash_attn_v3_kernel(const AttnParams p) {
   constexpr int QW = 32 * NQ, QB = 4 * QW, KT = 64, TILE = KT * 128;
@@ -515,7 +519,7 @@ flash_attn_v3_kernel(const AttnParams p) {
     constexpr bool MASK = decltype(mask_tag)::value;
     constexpr bool FIRST = decltype(first_tag)::value;   // LAZY == 3: the first key tile is peeled out of the loop
     constexpr float LAZY_BIG = 1024.0f;
-    const char* kbuf = smem + (t & 1) * 2 * TILE;
+    const char* kbuf = smem + (RING3 ? t % 3 : (t & 1)) * 2 * TILE;
     const char* vbuf = kbuf + TILE;
     f32x16 s[NQ][2];
     // ---- S^T = K Q^T for query blocks [q_lo, q_hi) (8 + 1 MFMAs per block, independent accumulators)
@@ -530,6 +534,26 @@ flash_attn_v3_kernel(const AttnParams p) {
           s[a][kb] = mfma32<T>(kaug, qaug[a], s[a][kb]);      // -m_run broadcast over the 32 keys
         }
       }
+      if constexpr (KPRE == 1) {
+        vec<T, 8> kfa[4][2];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb) kfa[ks][kb] = *reinterpret_cast<const vec<T, 8>*>(kbuf + swz_off(kb * 32 + lq, ks * 2 + h2));
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int qi = 0; qi < NQ; ++qi) {
+              if (qi < q_lo || qi >= q_hi) continue;
+              s[qi][kb] = mfma32<T>(kfa[ks][kb], qf[qi][ks], s[qi][kb]);
+            }
+#ifndef STAR_HOSTEMU
+        STAR_SCHED_GROUP(0x100, 8, 0);     // the eight ds_read_b128 first ...
+        STAR_SCHED_GROUP(0x008, 20, 0);    // ... then the MFMAs back to back
+#endif
+      } else {
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -541,6 +565,7 @@ flash_attn_v3_kernel(const AttnParams p) {
             s[qi][kb] = mfma32<T>(kf, qf[qi][ks], s[qi][kb]);
           }
         }
+      }
       if constexpr (MASK) {
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
@@ -636,6 +661,27 @@ flash_attn_v3_kernel(const AttnParams p) {
       lsum[qi] = (ls0 + ls1) + (ls2 + ls3);
     };
     auto pv = [&](int q_lo, int q_hi) {
+      if constexpr (RING3 == 1) {
+        // all V^T fragments first, then the LDS-DMA of tile t+2, then the MFMAs: hipcc puts a vmcnt(0) in front of the first
+        // transpose read that follows an LDS-DMA issue (it cannot tell the two apart), so the DMA is issued right BEHIND
+        // this tile's reads and gets a whole tile before the next such wait
+        vec<T, 8> vfa[4][2];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+          for (int db = 0; db < 2; ++db) vfa[tt][db] = load_vt_frag<T>(vbuf, tt * 16, db, lane);
+        if (t + 2 < nt) stage(t + 2, (t + 2) % 3);
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+          for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int qi = 0; qi < NQ; ++qi) {
+              if (qi < q_lo || qi >= q_hi) continue;
+              oacc[qi][db] = mfma32<T>(vfa[tt][db], pf[qi][tt], oacc[qi][db]);
+            }
+        return;
+      }
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
@@ -952,6 +998,19 @@ flash_attn_v3_kernel(const AttnParams p) {
       glds_wait(); block_sync();
       if (nt == 1) tile(0, std::true_type{}, std::true_type{});
       else tile(nt - 1, std::true_type{}, std::false_type{});
+    }
+  } else if constexpr (RING3 == 1) {
+    if (nt > 1) stage(1, 1);
+    for (int t = 0; t < nfull; ++t) {
+      // this wave's loads of tile t (4) were issued two tiles ago, those of tile t+1 (4) may stay in flight
+      if (t + 1 < nt) { STAR_WAIT_VMCNT(4); } else { STAR_WAIT_VMCNT(0); }
+      barrier_keep_dma();
+      tile(t, std::false_type{}, std::false_type{});   // issues the LDS-DMA of tile t+2 behind its V reads (slot read in tile t-1)
+    }
+    if (has_tail) {
+      STAR_WAIT_VMCNT(0);
+      barrier_keep_dma();
+      tile(nt - 1, std::true_type{}, std::false_type{});
     }
   } else {
     for (int t = 0; t < nfull; ++t) {

@@ -144,7 +144,7 @@ def ref_attention(q, k, v, heads):
     return o.transpose(1, 2).reshape(B, -1, heads * 64)
 
 
-@pytest.mark.parametrize("variant", [2, 4, 5, 6, 7, 8, 9, 10, 20])
+@pytest.mark.parametrize("variant", [2, 4, 5, 6, 7, 8, 9, 10, 20, 21, 22])
 @pytest.mark.parametrize("B,heads,Nq,Nk", [(2, 2, 300, 300), (1, 5, 80, 80), (3, 1, 257, 64), (1, 2, 64, 1), (9, 1, 33, 130), (1, 1, 130, 129)])
 def test_flash_attention_self(ctx, dtype, B, heads, Nq, Nk, variant):
     """spatial self-attention (unet_v2v.py:472 -> :184) on a fused QKV buffer, ragged q/k tails."""
@@ -169,7 +169,7 @@ def test_flash_attention_cross_77(ctx, dtype):
     assert_close(out, ref_attention(q, kv[..., :128], kv[..., 128:], heads), dtype, what="flash cross")
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 15, 20])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 15, 20, 21, 22])
 def test_flash_attention_variants_agree(ctx, dtype, variant):
     """all kernel variants (baseline / v2 / v3 with the augmented-k running max) against the fp32 reference, incl. a
     ragged key tail, strongly negative logits in tile 0 and a late spike that forces the rescale branch."""
@@ -185,7 +185,7 @@ def test_flash_attention_variants_agree(ctx, dtype, variant):
     assert_close(out, ref_attention(q, k, v, heads), dtype, scale=6.0, what=f"flash variant {variant}")
 
 
-@pytest.mark.parametrize("variant", [2, 6, 7, 8, 9, 10, 15, 20])
+@pytest.mark.parametrize("variant", [2, 6, 7, 8, 9, 10, 15, 20, 21, 22])
 def test_flash_attention_forced_rescale(ctx, dtype, variant):
     """a key spike late in the sequence forces the online-softmax rescale branch with a large max jump."""
     g = torch.Generator().manual_seed(11)
@@ -200,7 +200,7 @@ def test_flash_attention_forced_rescale(ctx, dtype, variant):
     assert_close(out, ref_attention(q, k, v, heads), dtype, what="flash rescale")
 
 
-@pytest.mark.parametrize("variant", [2, 6, 7, 8, 9, 10, 15, 20])
+@pytest.mark.parametrize("variant", [2, 6, 7, 8, 9, 10, 15, 20, 21, 22])
 def test_flash_attention_growing_max(ctx, dtype, variant):
     """scores that keep growing along the key axis (every tile moves the maximum by several binades, some by more than
     the fp16 exponent range) and a first tile far below everything that follows: the lazy-max variants must take their
