@@ -7,6 +7,15 @@
 //  temporal_attn_kernel : the per-pixel attention over the frame axis (K3;
 //      unet_v2v.py:479-489), one wavefront per (pixel, head), F <= 64.
 //
+// Variant map (AttnArgs::variant; profiles/r01_attn_ab.txt has every A/B):
+//   9  SHIPPED  flash_attn_v3_kernel<T, 2, LAZY=1, 0, ROWSUM=1>: scale + running max folded into the MFMA, lazy row maxima
+//               (the row sum of P is the overflow probe), fp32-add row sums.  Everything else is kept as a measured baseline:
+//   0 / 1      flash_attn_kernel / flash_attn_v2_kernel (first versions)        2 / 3   v3 without lazy maxima (NQ = 2 / 1)
+//   4 / 5      flash_attn_v4_kernel: software pipelining across key tiles       6 / 7   lazy maxima, one probe per tile / per block
+//   8          key-half pipeline      10 / 15  chunk pipeline (without / with sched_group_barrier patterns)
+//   20         flash_attn_v6_kernel: 512-thread workgroups, the two waves of a SIMD in enforced antiphase
+//   21 / 22    K fragments read ahead / K-V ring of three with counted vmcnt      11-14, 16, 17  ablation probes (bench only)
+//
 // Both compute S^T = K Q^T with the MFMA operands swapped, so a lane owns one
 // query row: its 32 scores per 64-key tile sit in its own registers, the row max
 // and row sum are lane-local (+ one exchange with lane^32), and the packed
