@@ -1,3 +1,4 @@
+# (FETCH_SIZE and WRITE_SIZE go in separate single-counter passes: a pass with FETCH_SIZE + TCC_HIT_sum + TCC_MISS_sum produced no output on this pool)
 # Round-end GPU run: full GPU test suite, bench under rocprofv3 (kernel trace + stats), PMC traffic passes of the
 # dominant kernel.  Usage on the GPU box: bash tools/final_run.sh   (outputs under gpurun_out/final/)
 set -x
@@ -11,7 +12,7 @@ timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_be
 tail -3 gpurun_out/final/bench.err
 tail -2 gpurun_out/final/bench.json | cut -c1-600
 find /tmp/prof_bench -name "*kernel_stats.csv" -exec cp {} gpurun_out/final/kernel_stats.csv \;
-timeout 150 rocprofv3 --pmc FETCH_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d /tmp/prof_fetch -- python tools/attn_l0_once.py > /dev/null 2>&1
+timeout 150 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/prof_fetch -- python tools/attn_l0_once.py > /dev/null 2>&1
 find /tmp/prof_fetch -name "*counter_collection.csv" -exec cp {} /tmp/fetch.csv \;
 timeout 150 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/prof_write -- python tools/attn_l0_once.py > /dev/null 2>&1
 find /tmp/prof_write -name "*counter_collection.csv" -exec cp {} /tmp/write.csv \;
