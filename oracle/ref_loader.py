@@ -39,6 +39,8 @@ def _install_stubs():
 
         def memory_efficient_attention(q, k, v, attn_bias=None, op=None):
             assert attn_bias is None
+            if q.dim() == 3:   # [B*h, N, d]: the 4-D form takes torch's memory-efficient CPU kernel (the 3-D form materialises
+                return F.scaled_dot_product_attention(q.unsqueeze(0), k.unsqueeze(0), v.unsqueeze(0)).squeeze(0)   # B*h x N x N logits)
             return F.scaled_dot_product_attention(q, k, v)
 
         xops.memory_efficient_attention = memory_efficient_attention

@@ -1,6 +1,7 @@
 // gemm.cpp -- tile selection + launch for gemm_kernel (see gemm.h).
 #include "ops.h"
 #include "gemm.h"
+#include "gemm8.h"
 
 namespace star {
 
@@ -35,6 +36,34 @@ static int launch_gemm_t(Ctx* ctx, const GemmArgs& a) {
   return launch_gemm_f<T, BM, BN, WM, WN, MINW, false, STAGGER, PIPE>(ctx, a);
 }
 
+// persistent phase-interleaved kernel (gemm8.h): one workgroup per CU walks its output tiles
+template <class T, bool RES>
+static int launch_gemm8_r(Ctx* ctx, const GemmArgs& a, int grid_cap) {
+  GemmParams p{};
+  p.A = a.A; p.W = a.W; p.C = a.C; p.bias = a.bias; p.res = a.res; p.zero_page = ctx->zero_page;
+  p.M = a.M; p.N = a.N; p.K = a.K; p.lda = a.lda; p.ldc = a.ldc; p.ldr = a.ldr;
+  p.H = a.H; p.Wd = a.Wd; p.Cin = a.Cin; p.Ho = a.Ho; p.Wo = a.Wo; p.stride = a.stride; p.pad_t = a.pad_t; p.pad_l = a.pad_l;
+  p.HW = a.HW; p.F = a.F; p.up_crop = a.up_crop; p.epi = a.epi;
+  p.tiles_m = (a.M + G8::BM - 1) / G8::BM;
+  p.tiles_n = (a.N + G8::BN - 1) / G8::BN;
+  const int nblk = p.tiles_m * p.tiles_n;
+  const int g = nblk <= grid_cap ? nblk : grid_cap;   // grid_cap is a multiple of 8 (XCD affinity of the tile walk)
+  dim3 grid((unsigned)g), block(G8::NT);
+  constexpr size_t smem = G8::SMEM_TOTAL;
+  switch (a.mode) {
+    case A_PLAIN: STAR_LAUNCH((gemm8_kernel<T, A_PLAIN, RES>), grid, block, smem, ctx->stream, p); break;
+    case A_CONV3X3: STAR_LAUNCH((gemm8_kernel<T, A_CONV3X3, RES>), grid, block, smem, ctx->stream, p); break;
+    case A_CONV3X3_UP: STAR_LAUNCH((gemm8_kernel<T, A_CONV3X3_UP, RES>), grid, block, smem, ctx->stream, p); break;
+    case A_TCONV3: STAR_LAUNCH((gemm8_kernel<T, A_TCONV3, RES>), grid, block, smem, ctx->stream, p); break;
+    default: return ctx->fail("gemm8: bad A mode");
+  }
+  return 0;
+}
+template <class T>
+static int launch_gemm8(Ctx* ctx, const GemmArgs& a, int grid_cap) {
+  return (a.epi & EPI_RES) ? launch_gemm8_r<T, true>(ctx, a, grid_cap) : launch_gemm8_r<T, false>(ctx, a, grid_cap);
+}
+
 template <class T>
 static int launch_gemm(Ctx* ctx, const GemmArgs& a) {
   int tile = a.force_tile;
@@ -62,6 +91,9 @@ static int launch_gemm(Ctx* ctx, const GemmArgs& a) {
     case 14: return launch_gemm_t<T, 256, 256, 2, 2, 1>(ctx, a);   // 4 waves x (128 x 128), one wave per SIMD, accumulators in AGPRs: 1/3 fewer LDS fragment reads
     case 9: return launch_gemm_t<T, 128, 256, 2, 2, 2, false, 3>(ctx, a);
     case 10: return launch_gemm_t<T, 128, 320, 2, 2, 2, false, 2>(ctx, a);
+    // (fp32 output -- VAE logits, final latent -- stays on the 2-stage tiles)
+    case 20: if (a.epi & EPI_OUT_F32) return launch_gemm_t<T, 256, 256, 4, 2, 2>(ctx, a); return launch_gemm8<T>(ctx, a, 256);   // persistent phase-interleaved 256 x 256 tile, one workgroup per CU
+    case 21: if (a.epi & EPI_OUT_F32) return launch_gemm_t<T, 256, 256, 4, 2, 2>(ctx, a); return launch_gemm8<T>(ctx, a, 8);     // the same on 8 workgroups (tests: several output tiles per workgroup)
   }
   if (tile >= 11 && tile <= 16 && tile != 14 && a.mode == A_PLAIN && !(a.epi & EPI_OUT_F32)) {   // ablation probes of the 256x256 main loop
     GemmParams p{};

@@ -214,6 +214,58 @@ STAR_DEV void barrier_keep_dma() {
 #endif
 }
 
+// workgroup barrier with NO wait at all in front of it (raw s_barrier): LDS-DMA and this wave's own ds_reads stay in flight
+// across it; the compiler still waits (lgkmcnt) before the first use of an LDS read's result.  Only for schedules whose
+// LDS hazards are covered by construction (gemm8.h).
+STAR_DEV void raw_barrier() {
+#ifdef STAR_HOSTEMU
+  ::star_emu::block_sync();
+#else
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+#endif
+}
+// wave-private LDS hand-over between lanes of ONE wave (ds_write by some lanes, ds_read of the same bytes by others): DS
+// operations of a wave execute in order, so only the compiler has to be kept from reordering them
+STAR_DEV void wave_lds_fence() {
+#ifdef STAR_HOSTEMU
+  int v = 0;
+  (void)::star_emu::wave_exchange(&v, 4);
+#else
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+}
+#ifdef STAR_HOSTEMU
+#define STAR_SETPRIO(n)
+#else
+#define STAR_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
+#endif
+
+// ---------------------------------------------------------------- buffer (descriptor) access
+// 16-byte loads / stores through a buffer descriptor: lanes whose byte offset is >= the descriptor's range read zeros /
+// store nothing, so row and column tails need no exec-masked branches (hipcc then counts every vmcnt wait exactly).
+// base and bytes must be wave-uniform.
+#ifdef STAR_HOSTEMU
+struct BufRsrc { char* base; uint32_t bytes; };
+STAR_DEV BufRsrc make_rsrc(const void* base, uint32_t bytes) { return BufRsrc{(char*)base, bytes}; }
+STAR_DEV u32x4 buf_load16(BufRsrc r, uint32_t voff) {
+  u32x4 v = {0u, 0u, 0u, 0u};
+  if ((uint64_t)voff + 16 <= r.bytes) memcpy(&v, r.base + voff, 16);
+  return v;
+}
+STAR_DEV void buf_store16(BufRsrc r, uint32_t voff, u32x4 v) {
+  if ((uint64_t)voff + 16 <= r.bytes) memcpy(r.base + voff, &v, 16);
+}
+#else
+using BufRsrc = __amdgpu_buffer_rsrc_t;
+STAR_DEV BufRsrc make_rsrc(const void* base, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+STAR_DEV u32x4 buf_load16(BufRsrc r, uint32_t voff) { return __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0); }
+STAR_DEV void buf_store16(BufRsrc r, uint32_t voff, u32x4 v) { __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff, 0, 0); }
+#endif
+
 // ---------------------------------------------------------------- transpose read
 // ds_read_b64_tr_b16: every lane passes the (8-byte aligned) LDS address of 4
 // contiguous 16-bit elements P[lane][0..3]; within each 16-lane group lane i
