@@ -33,6 +33,17 @@ build/emu/hostemu.o: tools/hostemu/hostemu.cpp $(CSRC)/hostemu.h
 tools/hostemu/libstar_emu.so: $(EMU_OBJS)
 	$(CLANGXX) -shared -fPIC $^ -o $@ -lm
 
+# bench-only build: the product sources + timing ablations / losing A/B variants (-DSTAR_BENCH_VARIANTS); loaded explicitly by tools/
+BENCH_OBJS := $(patsubst $(CSRC)/%.cpp,build/bench/%.o,$(SRCS))
+bench: tools/bench/libstar_hip_bench.so
+build/bench/attn.o: HIPFLAGS += -fno-honor-nans -fno-slp-vectorize
+build/bench/%.o: $(CSRC)/%.cpp $(wildcard $(CSRC)/*.h) include/star_hip.h
+	@mkdir -p build/bench
+	$(HIPCC) $(HIPFLAGS) -DSTAR_BENCH_VARIANTS=1 -c $< -o $@
+tools/bench/libstar_hip_bench.so: $(BENCH_OBJS)
+	@mkdir -p tools/bench
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC $^ -o $@
+
 clean:
-	rm -rf build star_amd/libstar_hip.so tools/hostemu/libstar_emu.so
-.PHONY: all hip emu clean
+	rm -rf build star_amd/libstar_hip.so tools/hostemu/libstar_emu.so tools/bench
+.PHONY: all hip emu bench clean

@@ -37,7 +37,7 @@ static int launch_gemm_t(Ctx* ctx, const GemmArgs& a) {
 }
 
 // persistent phase-interleaved kernel (gemm8.h): one workgroup per CU walks its output tiles
-template <class T, bool RES>
+template <class T, bool RES, int ABL = 0>
 static int launch_gemm8_r(Ctx* ctx, const GemmArgs& a, int grid_cap) {
   GemmParams p{};
   p.A = a.A; p.W = a.W; p.C = a.C; p.bias = a.bias; p.res = a.res; p.zero_page = ctx->zero_page;
@@ -51,10 +51,10 @@ static int launch_gemm8_r(Ctx* ctx, const GemmArgs& a, int grid_cap) {
   dim3 grid((unsigned)g), block(G8::NT);
   constexpr size_t smem = G8::SMEM_TOTAL;
   switch (a.mode) {
-    case A_PLAIN: STAR_LAUNCH((gemm8_kernel<T, A_PLAIN, RES>), grid, block, smem, ctx->stream, p); break;
-    case A_CONV3X3: STAR_LAUNCH((gemm8_kernel<T, A_CONV3X3, RES>), grid, block, smem, ctx->stream, p); break;
-    case A_CONV3X3_UP: STAR_LAUNCH((gemm8_kernel<T, A_CONV3X3_UP, RES>), grid, block, smem, ctx->stream, p); break;
-    case A_TCONV3: STAR_LAUNCH((gemm8_kernel<T, A_TCONV3, RES>), grid, block, smem, ctx->stream, p); break;
+    case A_PLAIN: STAR_LAUNCH((gemm8_kernel<T, A_PLAIN, RES, ABL>), grid, block, smem, ctx->stream, p); break;
+    case A_CONV3X3: STAR_LAUNCH((gemm8_kernel<T, A_CONV3X3, RES, ABL>), grid, block, smem, ctx->stream, p); break;
+    case A_CONV3X3_UP: STAR_LAUNCH((gemm8_kernel<T, A_CONV3X3_UP, RES, ABL>), grid, block, smem, ctx->stream, p); break;
+    case A_TCONV3: STAR_LAUNCH((gemm8_kernel<T, A_TCONV3, RES, ABL>), grid, block, smem, ctx->stream, p); break;
     default: return ctx->fail("gemm8: bad A mode");
   }
   return 0;
@@ -93,6 +93,16 @@ static int launch_gemm(Ctx* ctx, const GemmArgs& a) {
     case 10: return launch_gemm_t<T, 128, 320, 2, 2, 2, false, 2>(ctx, a);
     // (fp32 output -- VAE logits, final latent -- stays on the 2-stage tiles)
     case 20: if (a.epi & EPI_OUT_F32) return launch_gemm_t<T, 256, 256, 4, 2, 2>(ctx, a); return launch_gemm8<T>(ctx, a, 256);   // persistent phase-interleaved 256 x 256 tile, one workgroup per CU
+#ifdef STAR_BENCH_VARIANTS
+    case 31: return launch_gemm8_r<T, false, 1>(ctx, a, 256);   // timing ablations of gemm8 (garbage results)
+    case 32: return launch_gemm8_r<T, false, 2>(ctx, a, 256);
+    case 33: return launch_gemm8_r<T, false, 3>(ctx, a, 256);
+    case 34: return launch_gemm8_r<T, false, 4>(ctx, a, 256);
+    case 35: return launch_gemm8_r<T, false, 5>(ctx, a, 256);
+    case 36: return launch_gemm8_r<T, false, 6>(ctx, a, 256);
+    case 37: return launch_gemm8_r<T, false, 7>(ctx, a, 256);
+    case 38: return launch_gemm8_r<T, false, 8>(ctx, a, 256);
+#endif
     case 21: if (a.epi & EPI_OUT_F32) return launch_gemm_t<T, 256, 256, 4, 2, 2>(ctx, a); return launch_gemm8<T>(ctx, a, 8);     // the same on 8 workgroups (tests: several output tiles per workgroup)
   }
   if (tile >= 11 && tile <= 16 && tile != 14 && a.mode == A_PLAIN && !(a.epi & EPI_OUT_F32)) {   // ablation probes of the 256x256 main loop

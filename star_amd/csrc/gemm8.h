@@ -55,7 +55,8 @@ STAR_DEV void glds4(const void* gsrc, void* lds_wave_base) {
 #endif
 }
 
-template <class T, int AMODE, bool RES>   // RES: residual add in the epilogue (compile time: a run-time branch around the loads would make hipcc's vmcnt waits inexact)
+template <class T, int AMODE, bool RES, int ABL = 0>   // ABL: timing ablations (bench build only; results are garbage): 1 no DMA in the loop, 2 no fragment reads, 3 neither, 4 neither + no barriers, 5 neither + one barrier per phase, 6 DMA from a hot 64 KB region (always cache hits), 7 no A DMA, 8 no B DMA
+// RES: residual add in the epilogue (compile time: a run-time branch around the loads would make hipcc's vmcnt waits inexact)
 STAR_GLOBAL void STAR_LAUNCH_BOUNDS(512, 2)
 gemm8_kernel(const GemmParams p) {
   constexpr int BM = G8::BM, BN = G8::BN, BK = G8::BK;
@@ -113,7 +114,13 @@ gemm8_kernel(const GemmParams p) {
 
   auto a_issue = [&](const Pos& q, const int seq, const int s, const int off) STAR_ALWAYS_INLINE {
     if (!q.valid) return;
+    if (ABL == 1 || (ABL >= 3 && ABL <= 5) || ABL == 7) { if (seq >= 2) return; }
     char* dst = smem + (seq & 1) * G8::BUF + off;
+    if constexpr (ABL == 6) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) glds16(Ag + (size_t)(j * 128 + s * 64 + lrow) * p.lda + cc8, dst + (size_t)(j * 512 + wave * 64) * 16);
+      return;
+    }
     if constexpr (AMODE != A_PLAIN) {
       if (q.kt == 0) {
 #pragma unroll
@@ -162,7 +169,13 @@ gemm8_kernel(const GemmParams p) {
   };
   auto b_issue = [&](const Pos& q, const int seq, const int s, const int off) STAR_ALWAYS_INLINE {
     if (!q.valid) return;
+    if (ABL == 1 || (ABL >= 3 && ABL <= 5) || ABL == 8) { if (seq >= 2) return; }
     char* dst = smem + (seq & 1) * G8::BUF + off;
+    if constexpr (ABL == 6) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) glds16(Wg + (size_t)(j * 128 + s * 32 + b_row) * p.K + cc8, dst + (size_t)(j * 512 + wave * 64) * 16);
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       int n = q.n0 + j * 128 + s * 32 + b_row;
@@ -191,13 +204,16 @@ gemm8_kernel(const GemmParams p) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[sa][sb][i][r] = 0.f;
   };
+  bool abl_first = true;   // ABL >= 2: fragments are read once and kept (same operand statistics, no LDS traffic)
   auto read_A = [&](const char* part) STAR_ALWAYS_INLINE {
+    if (ABL >= 2 && ABL <= 5 && !abl_first) return;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) a[i][ks] = *reinterpret_cast<const vec<T, 8>*>(part + a_row0 + i * 4096 + fo[ks]);
   };
   auto read_B = [&](const char* part) STAR_ALWAYS_INLINE {
+    if (ABL >= 2 && ABL <= 5 && !abl_first) return;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) b[ks] = *reinterpret_cast<const vec<T, 8>*>(part + b_row0 + fo[ks]);
   };
@@ -210,6 +226,8 @@ gemm8_kernel(const GemmParams p) {
     STAR_SETPRIO(0);
   };
 
+  auto bar1 = [&]() STAR_ALWAYS_INLINE { if (ABL != 4) raw_barrier(); };
+  auto bar2 = [&]() STAR_ALWAYS_INLINE { if (ABL != 4 && ABL != 5) raw_barrier(); };
   // ---- stream positions: cur = the K tile being multiplied, n1 / n2 = one / two K tiles ahead
   Pos cur{};
   cur.it = 0;
@@ -233,9 +251,9 @@ gemm8_kernel(const GemmParams p) {
     read_B(buf + G8::OFF_B0);
     read_A(buf + G8::OFF_A0);
     a_issue(n1, seq + 1, 1, G8::OFF_A1);
-    raw_barrier();
+    bar1();
     mfma_q(acc[0][0]);
-    raw_barrier();
+    bar2();
     // ---- phase 1: (A0, B1)
     read_B(buf + G8::OFF_B1);
     if (cur.kt == 0) {   // this tile's bias slice (64 columns of this wave), by 4-byte LDS-DMA; covered by phase 3's wait
@@ -244,22 +262,22 @@ gemm8_kernel(const GemmParams p) {
       glds4(src, smem + G8::SMEM_BIAS + wave * 256);
     }
     b_issue(n1, seq + 1, 0, G8::OFF_B0);
-    raw_barrier();
+    bar1();
     mfma_q(acc[0][1]);
-    raw_barrier();
+    bar2();
     // ---- phase 2: (A1, B1)
     read_A(buf + G8::OFF_A1);
     a_issue(n2, seq, 0, G8::OFF_A0);
-    raw_barrier();
+    bar1();
     mfma_q(acc[1][1]);
-    raw_barrier();
+    bar2();
     // ---- phase 3: (A1, B0); the next K tile has landed after this wait
     read_B(buf + G8::OFF_B0);
     b_issue(n2, seq, 1, G8::OFF_B1);
-    if (n2.valid) { STAR_WAIT_VMCNT(4); } else { STAR_WAIT_VMCNT(0); }
-    raw_barrier();
+    if (n2.valid) { if (ABL == 7 || ABL == 8) { STAR_WAIT_VMCNT(2); } else { STAR_WAIT_VMCNT(4); } } else { STAR_WAIT_VMCNT(0); }
+    bar1();
     mfma_q(acc[1][0]);
-    raw_barrier();
+    bar2();
 
     if (cur.kt == nk - 1) {
       // ---------------------------------------------------------------- epilogue (wave-private, no workgroup barrier)
@@ -354,6 +372,7 @@ gemm8_kernel(const GemmParams p) {
       zero_acc();
     }
     cur = n1; n1 = n2; advance(n2);
+    abl_first = false;
   }
   if (wr == 0) raw_barrier();
 }

@@ -84,7 +84,8 @@ def main():
             (tok, 960, 320, "L0 qkv", False), (tok, 320, 320, "L0 proj", False), (tok, 2560, 320, "L0 geglu", True),
             (tok, 320, 1280, "L0 ff-out", False), (tok // 4, 1920, 640, "L1 qkv", False), (tok // 4, 5120, 640, "L1 geglu", True),
             (tok // 16 + 1536, 3840, 1280, "L2 qkv", False), (tok // 16 + 1536, 10240, 1280, "L2 geglu", True),
-            (8192, 8192, 8192, "square 8192", False),
+            (8192, 8192, 8192, "square 8192", False), (4096, 4096, 4096, "square 4096", False), (tok // 16 + 1536, 1280, 5120, "L2 ff-out", False),
+            (tok // 4, 640, 2560, "L1 ff-out", False), (tok, 1536, 512, "L0 tt qkv", False),
         ]:
             A = torch.randn(M, K, device=dev, dtype=dt)
             Wt = torch.randn(N, K, device=dev, dtype=dt) * 0.05
@@ -103,14 +104,23 @@ def main():
             w = torch.randn(Cout, 9 * Cin, device=dev, dtype=dt) * 0.02
             b = torch.randn(Cout, device=dev)
             out = torch.empty(NB * Hh * Ww, Cout, device=dev, dtype=dt)
-            s = timeit(lambda: ctx.gemm(x, w, bias=b, out=out, mode=L.A_CONV3X3, conv=(NB, Hh, Ww, Cin, Hh, Ww, 1, 1, 1)), iters=3, warmup=1)
-            rec(f"conv3x3 {tag}", s, flops=2.0 * NB * Hh * Ww * Cout * 9 * Cin)
+            for tile in ([0] if not args.tiles else [int(t) for t in args.tiles.split(",")]):
+                s = timeit(lambda: ctx.gemm(x, w, bias=b, out=out, mode=L.A_CONV3X3, conv=(NB, Hh, Ww, Cin, Hh, Ww, 1, 1, 1), force_tile=tile), iters=3, warmup=1)
+                rec(f"conv3x3 {tag} tile={tile}", s, flops=2.0 * NB * Hh * Ww * Cout * 9 * Cin)
             del x, w, out
         x = torch.randn(tok, 320, device=dev, dtype=dt)
         w = torch.randn(320, 960, device=dev, dtype=dt) * 0.02
         out = torch.empty(tok, 320, device=dev, dtype=dt)
-        s = timeit(lambda: ctx.gemm(x, w, out=out, res=x, mode=L.A_TCONV3, temporal=(F_, HW, 320)))
-        rec("tconv L0 320", s, flops=2.0 * tok * 320 * 960, bytes_=3 * tok * 320 * 2)
+        for tile in ([0] if not args.tiles else [int(t) for t in args.tiles.split(",")]):
+            s = timeit(lambda: ctx.gemm(x, w, out=out, res=x, mode=L.A_TCONV3, temporal=(F_, HW, 320), force_tile=tile))
+            rec(f"tconv L0 320 tile={tile}", s, flops=2.0 * tok * 320 * 960, bytes_=3 * tok * 320 * 2)
+        del x, w, out
+        x = torch.randn(tok // 16, 1280, device=dev, dtype=dt)
+        w = torch.randn(1280, 3840, device=dev, dtype=dt) * 0.02
+        out = torch.empty(tok // 16, 1280, device=dev, dtype=dt)
+        for tile in ([0] if not args.tiles else [int(t) for t in args.tiles.split(",")]):
+            s = timeit(lambda: ctx.gemm(x, w, out=out, res=x, mode=L.A_TCONV3, temporal=(F_, HW // 16, 1280), force_tile=tile))
+            rec(f"tconv L2 1280 tile={tile}", s, flops=2.0 * (tok // 16) * 1280 * 3840)
         del x, w, out
     if want("norm"):
         for C in (320, 1280):
