@@ -38,6 +38,8 @@ const char* star_last_error(star_ctx* ctx);
 int star_set_stream(star_ctx* ctx, void* hip_stream);   /* use the caller's hipStream_t */
 int star_sync(star_ctx* ctx);
 int star_is_hostemu(void);                               /* 1 only in the test-tooling emulator build */
+int star_has_bench_variants(void);                       /* 1 only in builds with -DSTAR_BENCH_VARIANTS (tools/bench, emulator): losing A/B
+                                                            kernels and timing ablations; the product library answers 0 and rejects their ids */
 size_t star_pool_bytes(star_ctx* ctx);
 size_t star_pool_peak_bytes(star_ctx* ctx);
 
@@ -50,7 +52,7 @@ typedef struct star_gemm_desc {
   int32_t HW, F;                     /* temporal-conv geometry */
   int32_t up_crop;                   /* STAR_A_CONV3X3_UP: rows cropped top+bottom after the 2x upsample (1 UNet, 0 VAE) */
   int32_t epi;                       /* STAR_EPI_* */
-  int32_t force_tile;                /* 0 = auto */
+  int32_t force_tile;                /* 0 = auto; 1 256x256, 2 256x320, 3 128x128, 4 256x128, 9 2 x (128x256); anything else: bench build only */
 } star_gemm_desc;
 /* replaces: nn.Linear / nn.Conv2d / nn.Conv3d(3,1,1) / nn.Conv1d(k=1) call sites
  * (unet_v2v.py:151-155,274,294,500,526,553,612,639,648,717,1005,1025,1209-1220) */
@@ -65,7 +67,8 @@ typedef struct star_attn_desc {
   int64_t bsq, bsk, bsv, bso;        /* batch (frame) strides in elements; 0 = shared by all batches */
   int32_t Nq, Nk, heads, batch;
   float scale;
-  int32_t variant;                   /* kernel variant: 9 (v3 + lazy row maxima, fp32 row sums) is the product; 0-8 are A/B baselines */
+  int32_t variant;                   /* 9 = the product kernel (0 is accepted as "default" = 9); any other id is rejected unless
+                                        the library was built with -DSTAR_BENCH_VARIANTS (some ablation ids compute wrong results) */
 } star_attn_desc;
 int star_attn_fwd(star_ctx* ctx, const star_attn_desc* d);
 

@@ -21,6 +21,14 @@ int star_is_hostemu(void) {
 #endif
 }
 
+int star_has_bench_variants(void) {
+#ifdef STAR_BENCH_VARIANTS
+  return 1;
+#else
+  return 0;
+#endif
+}
+
 int star_ctx_create(int device_id, int dtype, star_ctx** out) {
   if (!out) return 1;
   *out = nullptr;
@@ -77,7 +85,7 @@ int star_attn_fwd(star_ctx* h, const star_attn_desc* d) {
   a.Q = d->Q; a.K = d->K; a.V = d->V; a.O = d->O;
   a.ldq = d->ldq; a.ldk = d->ldk; a.ldv = d->ldv; a.ldo = d->ldo;
   a.bsq = d->bsq; a.bsk = d->bsk; a.bsv = d->bsv; a.bso = d->bso;
-  a.Nq = d->Nq; a.Nk = d->Nk; a.heads = d->heads; a.batch = d->batch; a.scale = d->scale; a.variant = d->variant;
+  a.Nq = d->Nq; a.Nk = d->Nk; a.heads = d->heads; a.batch = d->batch; a.scale = d->scale; a.variant = d->variant ? d->variant : 9;
   return op_flash_attn(&h->c, a);
 }
 int star_temporal_attn_fwd(star_ctx* h, const star_tattn_desc* d) {

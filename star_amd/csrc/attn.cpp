@@ -3,6 +3,9 @@
 #include <cstdlib>
 #include "ops.h"
 #include "attn.h"
+#ifdef STAR_BENCH_VARIANTS
+#include "attn_variants.h"
+#endif
 
 namespace star {
 
@@ -29,13 +32,18 @@ static int launch_flash(Ctx* ctx, const AttnArgs& a) {
     }
   }
 #endif
+  if (a.variant == 9) {   // the shipped kernel
+    STAR_LAUNCH((flash_attn_v3_kernel<T, 2, 1, 0, 1>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);
+    return 0;
+  }
+#ifdef STAR_BENCH_VARIANTS
+  // measured-and-lost A/B variants and ablation probes (several compute deliberately wrong results): bench build / emulator only
   if (a.variant == 0) STAR_LAUNCH((flash_attn_kernel<T>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);
   else if (a.variant == 1) STAR_LAUNCH((flash_attn_v2_kernel<T>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);
   else if (a.variant == 2) STAR_LAUNCH((flash_attn_v3_kernel<T, 2>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);
   else if (a.variant == 6) STAR_LAUNCH((flash_attn_v3_kernel<T, 2, 1>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);
   else if (a.variant == 7) STAR_LAUNCH((flash_attn_v3_kernel<T, 2, 2>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);
   else if (a.variant == 8) STAR_LAUNCH((flash_attn_v3_kernel<T, 2, 3>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);
-  else if (a.variant == 9) STAR_LAUNCH((flash_attn_v3_kernel<T, 2, 1, 0, 1>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);
   else if (a.variant == 10) STAR_LAUNCH((flash_attn_v3_kernel<T, 2, 4>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);
   else if (a.variant == 15) STAR_LAUNCH((flash_attn_v3_kernel<T, 2, 5>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);
   else if (a.variant == 11) STAR_LAUNCH((flash_attn_v3_kernel<T, 2, 1, 1>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);   // ablation probes of variant 6:
@@ -63,6 +71,9 @@ static int launch_flash(Ctx* ctx, const AttnArgs& a) {
     STAR_LAUNCH((flash_attn_v3_kernel<T, 1>), dim3((unsigned)nblk4), dim3(256), (size_t)32768, ctx->stream, p);
   }
   return 0;
+#else
+  return ctx->fail("flash_attn: variant ids other than 9 exist only in the bench build (make bench)");
+#endif
 }
 
 int op_flash_attn(Ctx* ctx, const AttnArgs& a) {

@@ -1,7 +1,9 @@
 // gemm.cpp -- tile selection + launch for gemm_kernel (see gemm.h).
 #include "ops.h"
 #include "gemm.h"
+#ifdef STAR_BENCH_VARIANTS
 #include "gemm8.h"
+#endif
 
 namespace star {
 
@@ -36,6 +38,7 @@ static int launch_gemm_t(Ctx* ctx, const GemmArgs& a) {
   return launch_gemm_f<T, BM, BN, WM, WN, MINW, false, STAGGER, PIPE>(ctx, a);
 }
 
+#ifdef STAR_BENCH_VARIANTS
 // persistent phase-interleaved kernel (gemm8.h): one workgroup per CU walks its output tiles
 template <class T, bool RES, int ABL = 0>
 static int launch_gemm8_r(Ctx* ctx, const GemmArgs& a, int grid_cap) {
@@ -64,6 +67,8 @@ static int launch_gemm8(Ctx* ctx, const GemmArgs& a, int grid_cap) {
   return (a.epi & EPI_RES) ? launch_gemm8_r<T, true>(ctx, a, grid_cap) : launch_gemm8_r<T, false>(ctx, a, grid_cap);
 }
 
+#endif
+
 template <class T>
 static int launch_gemm(Ctx* ctx, const GemmArgs& a) {
   int tile = a.force_tile;
@@ -82,18 +87,22 @@ static int launch_gemm(Ctx* ctx, const GemmArgs& a) {
     case 2: return launch_gemm_t<T, 256, 320, 4, 2, 2>(ctx, a);
     case 3: return launch_gemm_t<T, 128, 128, 2, 2, 2>(ctx, a);
     case 4: return launch_gemm_t<T, 256, 128, 4, 1, 1>(ctx, a);
+#ifdef STAR_BENCH_VARIANTS   // A/B experiments of round 1 / 2 that lost to the tiles above (profiles/r01_gemm_ablation.txt, r02_gemm8_ablation.txt)
     case 5: return launch_gemm_t<T, 256, 256, 4, 2, 2, true>(ctx, a);   // staggered wave groups (A/B)
     // (the 256x320 tile has no room for the carried fragments: 730+ VGPR spills when staggered)
     case 7: return launch_gemm_t<T, 256, 256, 4, 2, 2, false, 4>(ctx, a);   // pipelined main loop (ring of 4 x 32-k slots)
     case 8: return launch_gemm_t<T, 256, 320, 4, 2, 2, false, 4>(ctx, a);
-    // two independent 4-wave workgroups per CU (72 / 56 KB of LDS each): one group's epilogue and DMA latency hide
-    // behind the other group's MFMA burst
     case 14: return launch_gemm_t<T, 256, 256, 2, 2, 1>(ctx, a);   // 4 waves x (128 x 128), one wave per SIMD, accumulators in AGPRs: 1/3 fewer LDS fragment reads
-    case 9: return launch_gemm_t<T, 128, 256, 2, 2, 2, false, 3>(ctx, a);
     case 10: return launch_gemm_t<T, 128, 320, 2, 2, 2, false, 2>(ctx, a);
-    // (fp32 output -- VAE logits, final latent -- stays on the 2-stage tiles)
-    case 20: if (a.epi & EPI_OUT_F32) return launch_gemm_t<T, 256, 256, 4, 2, 2>(ctx, a); return launch_gemm8<T>(ctx, a, 256);   // persistent phase-interleaved 256 x 256 tile, one workgroup per CU
+#endif
+    // two independent 4-wave workgroups per CU (72 KB of LDS each): one group's epilogue and DMA latency hide behind the
+    // other group's MFMA burst (auto-selected for the short-K GEGLU layers)
+    case 9: return launch_gemm_t<T, 128, 256, 2, 2, 2, false, 3>(ctx, a);
 #ifdef STAR_BENCH_VARIANTS
+    // persistent phase-interleaved kernel (gemm8.h): correct and race-free on hardware, not faster than the 2-stage tiles on
+    // random operands (power-limited; profiles/r02_gemm8_ablation.txt).  fp32 output stays on the 2-stage tiles.
+    case 20: if (a.epi & EPI_OUT_F32) return launch_gemm_t<T, 256, 256, 4, 2, 2>(ctx, a); return launch_gemm8<T>(ctx, a, 256);
+    case 21: if (a.epi & EPI_OUT_F32) return launch_gemm_t<T, 256, 256, 4, 2, 2>(ctx, a); return launch_gemm8<T>(ctx, a, 8);   // 8 workgroups (tests: several output tiles per workgroup)
     case 31: return launch_gemm8_r<T, false, 1>(ctx, a, 256);   // timing ablations of gemm8 (garbage results)
     case 32: return launch_gemm8_r<T, false, 2>(ctx, a, 256);
     case 33: return launch_gemm8_r<T, false, 3>(ctx, a, 256);
@@ -103,8 +112,8 @@ static int launch_gemm(Ctx* ctx, const GemmArgs& a) {
     case 37: return launch_gemm8_r<T, false, 7>(ctx, a, 256);
     case 38: return launch_gemm8_r<T, false, 8>(ctx, a, 256);
 #endif
-    case 21: if (a.epi & EPI_OUT_F32) return launch_gemm_t<T, 256, 256, 4, 2, 2>(ctx, a); return launch_gemm8<T>(ctx, a, 8);     // the same on 8 workgroups (tests: several output tiles per workgroup)
   }
+#ifdef STAR_BENCH_VARIANTS
   if (tile >= 11 && tile <= 16 && tile != 14 && a.mode == A_PLAIN && !(a.epi & EPI_OUT_F32)) {   // ablation probes of the 256x256 main loop
     GemmParams p{};
     p.A = a.A; p.W = a.W; p.C = a.C; p.bias = a.bias; p.res = a.res; p.zero_page = ctx->zero_page;
@@ -119,7 +128,8 @@ static int launch_gemm(Ctx* ctx, const GemmArgs& a) {
     if (tile == 16) STAR_LAUNCH((gemm_kernel<T, 256, 256, 4, 2, A_PLAIN, 2, false, false, 5>), grid, block, smem, ctx->stream, p);   // no global stores
     return 0;
   }
-  return ctx->fail("gemm: bad tile id");
+#endif
+  return ctx->fail("gemm: bad tile id (experimental tiles exist only in the bench build)");
 }
 
 int op_gemm(Ctx* ctx, const GemmArgs& a) {

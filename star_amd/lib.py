@@ -93,6 +93,7 @@ class Library:
         c = self.cdll
         vp, i32, i64, sz = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t
         self.is_hostemu = bool(_sig(c, "star_is_hostemu", i32)())
+        self.has_bench_variants = bool(_sig(c, "star_has_bench_variants", i32)())
         self.ctx_create = _sig(c, "star_ctx_create", i32, i32, i32, ctypes.POINTER(vp))
         self.ctx_destroy = _sig(c, "star_ctx_destroy", None, vp)
         self.last_error = _sig(c, "star_last_error", ctypes.c_char_p, vp)

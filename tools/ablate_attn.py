@@ -4,7 +4,7 @@ import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from star_amd import lib as L
-ctx = L.Context(0, torch.float16)
+ctx = L.Context(0, torch.float16, L.Library(os.path.join(os.path.dirname(os.path.abspath(__file__)), "bench", "libstar_hip_bench.so")))   # bench build: make bench
 dev = ctx.torch_device
 B, heads, N = 8, 5, 26352
 C = heads * 64

@@ -6,7 +6,7 @@ M, N, K = (int(x) for x in sys.argv[1:4])
 tiles = [int(t) for t in sys.argv[4].split(",")]
 iters = int(sys.argv[5]) if len(sys.argv) > 5 else 3
 dt = torch.float16
-ctx = L.Context(0, dt)
+ctx = L.Context(0, dt, L.Library(os.path.join(os.path.dirname(os.path.abspath(__file__)), "bench", "libstar_hip_bench.so")))   # bench build: make bench
 A = torch.randn(M, K, device="cuda", dtype=dt)
 W = torch.randn(N, K, device="cuda", dtype=dt) * 0.05
 out = torch.empty(M, N, device="cuda", dtype=dt)

@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from star_amd import lib as L
 
 dt = torch.float16
-ctx = L.Context(0, dt)
+ctx = L.Context(0, dt, L.Library(os.path.join(os.path.dirname(os.path.abspath(__file__)), "bench", "libstar_hip_bench.so")))   # bench build: make bench
 dev = ctx.torch_device
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 shapes = [(843264 // 8, 960, 320, 0), (843264 // 8, 2560, 320, 1), (214272 // 2, 1920, 640, 0), (55296, 3840, 1280, 0), (8192, 8192, 2048, 0),
