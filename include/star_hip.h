@@ -32,6 +32,9 @@ enum { STAR_EPI_BIAS = 1, STAR_EPI_RES = 2, STAR_EPI_GEGLU = 4, STAR_EPI_OUT_F32
 
 /* ---- context ------------------------------------------------------------ */
 /* replaces: VideoToVideo_sr.__init__ device selection (video_to_video_model.py:21-34,42) */
+/* returns 0, or: 1 null out, 2 bad dtype, 3 no such device, 4 hipSetDevice failed, 5 out of memory, 6 the device is not a gfx950
+ * with the 160 KB LDS opt-in (the library carries gfx950 code objects only; there is no fallback path).
+ * Every compute entry point below returns non-zero and sets star_last_error() when one of its kernels could not be launched. */
 int star_ctx_create(int device_id, int dtype, star_ctx** out);
 void star_ctx_destroy(star_ctx* ctx);
 const char* star_last_error(star_ctx* ctx);

@@ -11,6 +11,28 @@ using namespace star;
 
 struct star_ctx { Ctx c; };
 
+// ---- launch-status plumbing: STAR_LAUNCH (prim.h) records the first refused launch / attribute here; every compute entry point
+// of the ABI ends in finish(), which turns it into a non-zero return code + star_last_error() text.  Without this a forward whose
+// kernels never ran (no gfx950 code object, LDS opt-in refused) would return 0 with uninitialised output buffers.
+static thread_local std::string g_launch_err;
+namespace star {
+void rt_note_launch_error(const char* what) {
+  if (!g_launch_err.empty()) return;
+  g_launch_err = what;
+  g_launch_err += ": ";
+  g_launch_err += rt::last_error_string();   // also clears HIP's sticky "last error"
+}
+}
+static int finish(star_ctx* h, int rc) {
+  if (rc) { g_launch_err.clear(); return rc; }
+  if (!g_launch_err.empty()) {
+    const std::string e = "kernel launch failed: " + g_launch_err;
+    g_launch_err.clear();
+    return h->c.fail(e);
+  }
+  return 0;
+}
+
 extern "C" {
 
 int star_is_hostemu(void) {
@@ -35,6 +57,7 @@ int star_ctx_create(int device_id, int dtype, star_ctx** out) {
   if (dtype != DT_F16 && dtype != DT_BF16) return 2;
   if (rt::device_count() <= device_id) return 3;  // no CPU fallback: a gfx950 device is required
   if (rt::set_device(device_id)) return 4;
+  if (!rt::device_is_gfx950(device_id)) return 6;   // the code objects are gfx950-only and the GEMM tiles need the 160 KB LDS opt-in
   star_ctx* h = new star_ctx();
   h->c.device = device_id;
   h->c.dtype = dtype;
@@ -75,7 +98,7 @@ int star_gemm(star_ctx* h, const star_gemm_desc* d) {
   a.mode = d->mode; a.H = d->H; a.Wd = d->Wd; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo;
   a.stride = d->stride; a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.HW = d->HW; a.F = d->F; a.up_crop = d->up_crop;
   a.epi = d->epi; a.force_tile = d->force_tile;
-  return op_gemm(&h->c, a);
+  return finish(h, op_gemm(&h->c, a));
 }
 
 
@@ -86,7 +109,7 @@ int star_attn_fwd(star_ctx* h, const star_attn_desc* d) {
   a.ldq = d->ldq; a.ldk = d->ldk; a.ldv = d->ldv; a.ldo = d->ldo;
   a.bsq = d->bsq; a.bsk = d->bsk; a.bsv = d->bsv; a.bso = d->bso;
   a.Nq = d->Nq; a.Nk = d->Nk; a.heads = d->heads; a.batch = d->batch; a.scale = d->scale; a.variant = d->variant ? d->variant : 9;
-  return op_flash_attn(&h->c, a);
+  return finish(h, op_flash_attn(&h->c, a));
 }
 int star_temporal_attn_fwd(star_ctx* h, const star_tattn_desc* d) {
   if (h) rt::set_device(h->c.device);   // follow the context's device, not the caller's current one
@@ -94,42 +117,42 @@ int star_temporal_attn_fwd(star_ctx* h, const star_tattn_desc* d) {
   a.Q = d->Q; a.K = d->K; a.V = d->V; a.O = d->O;
   a.ldq = d->ldq; a.ldk = d->ldk; a.ldv = d->ldv; a.ldo = d->ldo;
   a.F = d->F; a.HW = d->HW; a.heads = d->heads; a.scale = d->scale;
-  return op_temporal_attn(&h->c, a);
+  return finish(h, op_temporal_attn(&h->c, a));
 }
 int star_group_norm(star_ctx* h, const void* x, int32_t ldx, void* y, int32_t ldy, const float* gamma,
                     const float* beta, int32_t rows, int32_t C, int32_t rows_per_stat, float eps, int32_t silu) {
   if (h) rt::set_device(h->c.device);   // follow the context's device, not the caller's current one
-  return op_group_norm(&h->c, x, ldx, y, ldy, gamma, beta, rows, C, rows_per_stat, eps, silu != 0);
+  return finish(h, op_group_norm(&h->c, x, ldx, y, ldy, gamma, beta, rows, C, rows_per_stat, eps, silu != 0));
 }
 int star_layer_norm(star_ctx* h, const void* x, int32_t ldx, void* y, int32_t ldy, const float* gamma,
                     const float* beta, int32_t rows, int32_t C, float eps, int32_t mode, const float* gate_w,
                     float* maps, int32_t H, int32_t W) {
   if (h) rt::set_device(h->c.device);   // follow the context's device, not the caller's current one
-  return op_layer_norm(&h->c, x, ldx, y, ldy, gamma, beta, rows, C, eps, mode, gate_w, maps, H, W);
+  return finish(h, op_layer_norm(&h->c, x, ldx, y, ldy, gamma, beta, rows, C, eps, mode, gate_w, maps, H, W));
 }
 int star_concat_add(star_ctx* h, const void* a, const void* b, const void* c, void* out, int32_t rows, int32_t C1, int32_t C2) {
   if (h) rt::set_device(h->c.device);   // follow the context's device, not the caller's current one
-  return op_concat_add(&h->c, a, b, c, out, rows, C1, C2);
+  return finish(h, op_concat_add(&h->c, a, b, c, out, rows, C1, C2));
 }
 int star_add(star_ctx* h, const void* a, const void* b, void* out, int64_t n) {
   if (h) rt::set_device(h->c.device);
-  return op_add(&h->c, a, b, out, n);
+  return finish(h, op_add(&h->c, a, b, out, n));
 }
 int star_stem_im2col(star_ctx* h, const float* latent, void* out, int32_t Cl, int32_t F, int32_t H, int32_t W) {
   if (h) rt::set_device(h->c.device);   // follow the context's device, not the caller's current one
-  return op_stem_im2col(&h->c, latent, out, Cl, F, H, W);
+  return finish(h, op_stem_im2col(&h->c, latent, out, Cl, F, H, W));
 }
 int star_rows_to_latent(star_ctx* h, const float* rows, float* out, int32_t Cl, int32_t ld, int64_t ntok) {
   if (h) rt::set_device(h->c.device);   // follow the context's device, not the caller's current one
-  return op_rows_to_latent(&h->c, rows, out, Cl, ld, ntok);
+  return finish(h, op_rows_to_latent(&h->c, rows, out, Cl, ld, ntok));
 }
 int star_gemv(star_ctx* h, const float* x, const void* W, const float* b, float* y, int32_t N, int32_t K, int32_t silu_in, int32_t silu_out) {
   if (h) rt::set_device(h->c.device);   // follow the context's device, not the caller's current one
-  return op_gemv(&h->c, x, W, b, y, N, K, silu_in != 0, silu_out != 0);
+  return finish(h, op_gemv(&h->c, x, W, b, y, N, K, silu_in != 0, silu_out != 0));
 }
 int star_cast(star_ctx* h, const float* x, void* y, int64_t n) {
   if (h) rt::set_device(h->c.device);
-  return op_cast(&h->c, x, y, n);
+  return finish(h, op_cast(&h->c, x, y, n));
 }
 
 
@@ -156,23 +179,23 @@ int star_unet_build(star_ctx* h, const star_unet_config* c) {
   if (cfg.head_dim != 64) return h->c.fail("unet_build: head_dim must be 64");
   if (cfg.dim % 64) return h->c.fail("unet_build: dim must be a multiple of 64");
   if (cfg.n_levels < 1 || cfg.n_levels > 8) return h->c.fail("unet_build: bad n_levels");
-  return unet_build(&h->c, cfg);
+  return finish(h, unet_build(&h->c, cfg));
 }
 int star_unet_forward(star_ctx* h, const float* xt, int64_t t, const float* y, const float* hint, float* out, int32_t f, int32_t hh, int32_t w) {
   if (h) rt::set_device(h->c.device);   // follow the context's device, not the caller's current one
-  return unet_forward(&h->c, xt, (long long)t, y, hint, out, f, hh, w);
+  return finish(h, unet_forward(&h->c, xt, (long long)t, y, hint, out, f, hh, w));
 }
 int star_unet_forward_cfg(star_ctx* h, const float* xt, int64_t t, const float* y_cond, const float* y_uncond, const float* hint,
                           float* out_cond, float* out_uncond, int32_t f, int32_t hh, int32_t w) {
   if (h) rt::set_device(h->c.device);
   const float* ys[2] = {y_cond, y_uncond};
   float* outs[2] = {out_cond, out_uncond};
-  return unet_forward_n(&h->c, xt, (long long)t, ys, hint, outs, 2, f, hh, w);
+  return finish(h, unet_forward_n(&h->c, xt, (long long)t, ys, hint, outs, 2, f, hh, w));
 }
 int star_module_run(star_ctx* h, int32_t kind, const char* prefix, int32_t cin, int32_t cout, int32_t heads, int32_t embed_dim,
                     int32_t context_dim, const void* x, const float* emb, const float* context, void* out, int32_t f, int32_t hh, int32_t w) {
   if (h) rt::set_device(h->c.device);   // follow the context's device, not the caller's current one
-  return module_run(&h->c, kind, prefix, cin, cout, heads, embed_dim, context_dim, x, emb, context, out, f, hh, w);
+  return finish(h, module_run(&h->c, kind, prefix, cin, cout, heads, embed_dim, context_dim, x, emb, context, out, f, hh, w));
 }
 
 
@@ -184,19 +207,19 @@ int star_vae_build(star_ctx* h, const star_vae_config* c) {
   cfg.layers_per_block = c->layers_per_block;
   if (cfg.n_blocks < 1 || cfg.n_blocks > 8) return h->c.fail("vae_build: bad n_blocks");
   for (int i = 0; i < cfg.n_blocks; ++i) if (cfg.block_out[i] % 64) return h->c.fail("vae_build: block_out channels must be multiples of 64");
-  return vae_build(&h->c, cfg);
+  return finish(h, vae_build(&h->c, cfg));
 }
 int star_vae_encode(star_ctx* h, const float* x, float* moments, int32_t n, int32_t H, int32_t W) {
   if (h) rt::set_device(h->c.device);
-  return vae_encode(&h->c, x, moments, n, H, W);
+  return finish(h, vae_encode(&h->c, x, moments, n, H, W));
 }
 int star_vae_decode(star_ctx* h, const float* z, float* out, int32_t n, int32_t hh, int32_t w) {
   if (h) rt::set_device(h->c.device);
-  return vae_decode(&h->c, z, out, n, hh, w);
+  return finish(h, vae_decode(&h->c, z, out, n, hh, w));
 }
 int star_softmax_rows(star_ctx* h, const float* s, int32_t lds, void* p, int32_t ldp, int32_t rows, int32_t n, float scale) {
   if (h) rt::set_device(h->c.device);   // follow the context's device, not the caller's current one
-  return op_softmax_rows(&h->c, s, lds, p, ldp, rows, n, scale);
+  return finish(h, op_softmax_rows(&h->c, s, lds, p, ldp, rows, n, scale));
 }
 
 
@@ -204,25 +227,25 @@ int star_resize_pad(star_ctx* h, const float* src, float* dst, int32_t planes, i
                     int32_t pad_l, int32_t pad_r, int32_t pad_t, int32_t pad_b, float pad_value) {
   if (!h) return -1;
   rt::set_device(h->c.device);
-  return op_resize_pad(&h->c, src, dst, planes, hh, w, th, tw, pad_l, pad_r, pad_t, pad_b, pad_value);
+  return finish(h, op_resize_pad(&h->c, src, dst, planes, hh, w, th, tw, pad_l, pad_r, pad_t, pad_b, pad_value));
 }
 int star_plane_stats(star_ctx* h, const float* x, float* stats, int32_t planes, int64_t n, float scale, float shift,
                      int32_t clamp01, float eps) {
   if (!h) return -1;
   rt::set_device(h->c.device);
-  return op_plane_stats(&h->c, x, stats, planes, (long long)n, scale, shift, clamp01 != 0, eps);
+  return finish(h, op_plane_stats(&h->c, x, stats, planes, (long long)n, scale, shift, clamp01 != 0, eps));
 }
 int star_color_fix(star_ctx* h, const float* x, const float* src, float* out, int32_t F, int32_t C, int32_t H, int32_t W,
                    int32_t hh, int32_t w) {
   if (!h) return -1;
   rt::set_device(h->c.device);
-  return op_color_fix(&h->c, x, true, src, out, F, C, H, W, hh, w);
+  return finish(h, op_color_fix(&h->c, x, true, src, out, F, C, H, W, hh, w));
 }
 int star_adain_color_fix(star_ctx* h, const float* target, const float* src, float* out, int32_t F, int32_t C, int32_t H, int32_t W,
                          int32_t hh, int32_t w) {
   if (!h) return -1;
   rt::set_device(h->c.device);
-  return op_color_fix(&h->c, target, false, src, out, F, C, H, W, hh, w);
+  return finish(h, op_color_fix(&h->c, target, false, src, out, F, C, H, W, hh, w));
 }
 
 int star_profile_begin(star_ctx* h) {

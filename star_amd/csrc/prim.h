@@ -449,14 +449,27 @@ STAR_DEV float fast_rcp(float x) {
 }  // namespace star
 
 // ---------------------------------------------------------------- launch
+namespace star {
+// first failed launch since the last check (name of the kernel + HIP error string); defined in api.cpp
+void rt_note_launch_error(const char* what);
+}
 #ifdef STAR_HOSTEMU
 #define STAR_LAUNCH(kern, grid, block, smem, stream, ...) \
   ::star_emu::launch((grid), (block), (smem), [&]() { kern(__VA_ARGS__); })
 #else
+// The dynamic-LDS opt-in (> 64 KB) is set once per kernel instantiation and call site, and a refused attribute or launch is
+// remembered in star::rt::launch_error (checked at the end of every C-ABI call: include/star_hip.h), never dropped.
 #define STAR_LAUNCH(kern, grid, block, smem, stream, ...)                                              \
   do {                                                                                                  \
-    if ((smem) > 65536)                                                                                 \
-      (void)hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(smem)); \
+    if ((smem) > 65536) {                                                                               \
+      static size_t star_attr_set_ = 0;                                                                 \
+      if ((size_t)(smem) > star_attr_set_) {                                                            \
+        if (hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(smem)) != hipSuccess) \
+          ::star::rt_note_launch_error(#kern ": dynamic LDS size refused");                             \
+        star_attr_set_ = (size_t)(smem);                                                                \
+      }                                                                                                 \
+    }                                                                                                   \
     hipLaunchKernelGGL(kern, (grid), (block), (smem), (stream), __VA_ARGS__);                           \
+    if (hipPeekAtLastError() != hipSuccess) ::star::rt_note_launch_error(#kern);                        \
   } while (0)
 #endif

@@ -17,6 +17,7 @@ inline int memcpy_d2d(void* d, const void* s, size_t n, hipStream_t) { memcpy(d,
 inline int stream_sync(hipStream_t) { return 0; }
 inline int set_device(int) { return 0; }
 inline int device_count() { return 1; }
+inline bool device_is_gfx950(int) { return true; }
 inline const char* last_error_string() { return "hostemu"; }
 inline int peek_error() { return 0; }
 inline void* event_record(hipStream_t) { return nullptr; }
@@ -33,6 +34,11 @@ inline int stream_sync(hipStream_t s) { return hipStreamSynchronize(s) != hipSuc
 inline int set_device(int d) { return hipSetDevice(d) != hipSuccess; }
 inline int device_count() { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 inline const char* last_error_string() { return hipGetErrorString(hipGetLastError()); }
+inline bool device_is_gfx950(int d) {
+  hipDeviceProp_t pr;
+  if (hipGetDeviceProperties(&pr, d) != hipSuccess) return false;
+  return strncmp(pr.gcnArchName, "gfx950", 6) == 0 && pr.sharedMemPerBlockOptin >= 160 * 1024;
+}
 inline int peek_error() { return hipPeekAtLastError() != hipSuccess; }
 inline void* event_record(hipStream_t s) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; (void)hipEventRecord(e, s); return (void*)e; }
 inline float event_elapsed_ms(void* a, void* b) { float ms = 0.f; if (a && b) { (void)hipEventSynchronize((hipEvent_t)b); (void)hipEventElapsedTime(&ms, (hipEvent_t)a, (hipEvent_t)b); } return ms; }

@@ -150,7 +150,9 @@ class Context:
         h = ctypes.c_void_p()
         rc = self.lib.ctx_create(self.device_index, _TORCH2STAR[dtype], ctypes.byref(h))
         if rc:
-            raise StarError(f"star_ctx_create failed (rc={rc})")
+            why = {2: "unsupported dtype", 3: "no such device", 4: "hipSetDevice failed", 5: "out of device memory",
+                   6: "the device is not a gfx950 (MI355X) with the 160 KB LDS opt-in"}.get(rc, "")
+            raise StarError(f"star_ctx_create failed (rc={rc}) {why}")
         self.h = h
         if not self.lib.is_hostemu:
             self.lib.set_stream(self.h, ctypes.c_void_p(torch.cuda.current_stream(self.device_index).cuda_stream))

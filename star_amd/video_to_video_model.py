@@ -6,7 +6,8 @@ noise seed) -- with the denoiser and the VAE running as hand-written HIP kernels
 
 Differences forced by the offline image (all explicit, none silent):
   * open_clip is not installed: `input['y']` / `negative_y` may be given as precomputed [1, 77, 1024] embeddings;
-    a prompt *string* needs `opt.text_encoder` (any callable str -> [1, 77, 1024]) or an importable open_clip.
+    a prompt *string* needs `opt.text_encoder` (any callable str -> [1, 77, 1024]), an importable open_clip, or
+    `opt.text_state_dict` + `opt.tokenizer` (star_amd/modules/embedder.py restates the OpenCLIP text tower).
   * diffusers / HF hub are not available: the VAE weights come from `opt.vae_path` (a state dict with diffusers'
     AutoencoderKLTemporalDecoder keys) or `opt.vae_state_dict`.
   * `opt.dtype` selects fp16 (reference: generator.half() + autocast, :42,98) or bf16 storage for the HIP path.
@@ -58,14 +59,18 @@ class VideoToVideo_sr:
         dev_index = self.device.index or 0
         library = _opt(opt, "library")             # tests may pass the emulator build explicitly
 
-        # text encoder (video_to_video_model.py:26-29): optional here, see module docstring
+        # text encoder (video_to_video_model.py:26-29).  opt.text_encoder: any callable str -> [1, 77, 1024]; otherwise the
+        # OpenCLIP wrapper (star_amd/modules/embedder.py) from open_clip itself or from opt.text_state_dict (+ opt.tokenizer).
+        # Built lazily: a pipeline that only ever sees precomputed embeddings never needs it.
         self.text_encoder = _opt(opt, "text_encoder")
+        self._text_encoder_error = None
         if self.text_encoder is None:
             try:
                 from .modules.embedder import FrozenOpenCLIPEmbedder
-                self.text_encoder = FrozenOpenCLIPEmbedder(device=self.device, pretrained="laion2b_s32b_b79k")
-            except ImportError:
-                self.text_encoder = None
+                self.text_encoder = FrozenOpenCLIPEmbedder(device=self.device, pretrained="laion2b_s32b_b79k",
+                                                           text_state_dict=_opt(opt, "text_state_dict"), tokenizer=_opt(opt, "tokenizer"))
+            except ImportError as e:     # open_clip missing and no weights / tokenizer given: only prompt STRINGS are affected
+                self._text_encoder_error = str(e)
 
         # U-Net with ControlNet (:32-43)
         unet_cfg = _opt(opt, "unet_config", UNetConfig())
@@ -123,8 +128,8 @@ class VideoToVideo_sr:
         if torch.is_tensor(y):
             return y.detach()
         if self.text_encoder is None:
-            raise RuntimeError("a prompt string needs a text encoder: open_clip is not installed in this image; pass "
-                               "precomputed [1, 77, 1024] embeddings or opt.text_encoder")
+            raise RuntimeError("a prompt string needs a text encoder: " + (self._text_encoder_error or
+                               "pass precomputed [1, 77, 1024] embeddings or opt.text_encoder"))
         return self.text_encoder(y).detach()
 
     def test(self, input: Dict[str, Any], total_noise_levels=1000, steps=50, solver_mode="fast", guide_scale=7.5, max_chunk_len=32,

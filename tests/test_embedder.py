@@ -1,0 +1,70 @@
+"""Text-encoder wrapper (star_amd/modules/embedder.py; reference video_to_video/modules/embedder.py:12-72): the prompt-string path
+with a stub tokenizer, the penultimate-layer rule, the causal mask, and the restated OpenCLIP text block against an independent
+statement on F.multi_head_attention_forward.  open_clip is not installed in this image: PARITY UNPINNED against open_clip itself."""
+import pytest
+import torch
+
+from star_amd.modules.embedder import FrozenOpenCLIPEmbedder, OpenCLIPTextTransformer, reference_block
+
+torch.set_grad_enabled(False)
+
+
+def small_tower(layers=3):
+    torch.manual_seed(0)
+    m = OpenCLIPTextTransformer(vocab_size=100, context_length=77, width=64, heads=4, layers=layers)
+    for p in m.parameters():
+        if p.dim() == 1:
+            p.add_(torch.randn_like(p) * 0.1)
+    return m
+
+
+def tok(text):
+    texts = [text] if isinstance(text, str) else text
+    out = torch.zeros(len(texts), 77, dtype=torch.long)
+    for i, t in enumerate(texts):
+        ids = [1] + [3 + (ord(c) % 90) for c in t][:75] + [2]
+        out[i, :len(ids)] = torch.tensor(ids)
+    return out
+
+
+def test_prompt_string_goes_through_tokenizer_and_stops_one_block_early():
+    m = small_tower(3)
+    emb = FrozenOpenCLIPEmbedder(device="cpu", model=m, tokenizer=tok)
+    z = emb("a cat")
+    assert z.shape == (1, 77, 64) and z.dtype == torch.float32
+    sd = {k: v for k, v in m.state_dict().items()}
+    x = (m.token_embedding(tok("a cat")) + m.positional_embedding).permute(1, 0, 2)
+    for i in range(2):    # 3 blocks, 'penultimate' -> the first two
+        p = {k[len(f"transformer.resblocks.{i}."):]: v for k, v in sd.items() if k.startswith(f"transformer.resblocks.{i}.")}
+        x = reference_block(x, p, 4, m.attn_mask)
+    ref = torch.nn.functional.layer_norm(x.permute(1, 0, 2), (64,), sd["ln_final.weight"], sd["ln_final.bias"])
+    assert float((z - ref).abs().max()) < 2e-5
+    last = FrozenOpenCLIPEmbedder(device="cpu", model=m, tokenizer=tok, layer="last")("a cat")
+    assert float((last - z).abs().max()) > 1e-3
+
+
+def test_causal_mask_later_tokens_do_not_leak_backwards():
+    m = small_tower(2)
+    emb = FrozenOpenCLIPEmbedder(device="cpu", model=m, tokenizer=tok, layer="last")
+    a, b = emb("hello world"), emb("hello there")
+    assert float((a[0, :6] - b[0, :6]).abs().max()) == 0.0      # <start> + "hello" are identical, what follows must not matter
+    assert float((a[0, 8:] - b[0, 8:]).abs().max()) > 0
+
+
+def test_state_dict_surface_matches_open_clip_names():
+    keys = set(OpenCLIPTextTransformer(100, 77, 64, 4, 1).state_dict())
+    assert {"token_embedding.weight", "positional_embedding", "ln_final.weight", "transformer.resblocks.0.attn.in_proj_weight",
+            "transformer.resblocks.0.attn.out_proj.bias", "transformer.resblocks.0.mlp.c_fc.weight",
+            "transformer.resblocks.0.mlp.c_proj.bias", "transformer.resblocks.0.ln_1.weight", "transformer.resblocks.0.ln_2.bias"} <= keys
+    full = {"visual.proj": torch.zeros(1), "logit_scale": torch.zeros(()), **OpenCLIPTextTransformer(100, 77, 64, 4, 1).state_dict()}
+    OpenCLIPTextTransformer(100, 77, 64, 4, 1).load_text_state_dict(full)
+
+
+def test_missing_open_clip_is_reported_only_when_a_string_needs_it():
+    try:
+        import open_clip  # noqa: F401
+        pytest.skip("open_clip is installed")
+    except ImportError:
+        pass
+    with pytest.raises(ImportError):
+        FrozenOpenCLIPEmbedder(device="cpu")

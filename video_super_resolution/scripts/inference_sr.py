@@ -67,6 +67,8 @@ def parse_args():
     p.add_argument("--dtype", type=str, default="f16", choices=["f16", "bf16"])
     p.add_argument("--prompt_embedding", type=str, default="")
     p.add_argument("--negative_embedding", type=str, default="")
+    p.add_argument("--text_encoder_path", type=str, default="",
+                   help="open_clip ViT-H-14 state dict for the text tower (tokenisation still needs the open_clip package)")
     return p.parse_args()
 
 
@@ -75,7 +77,8 @@ def main():
     assert a.solver_mode in ("fast", "normal")
     star = STAR(result_dir=a.save_dir, file_name=a.file_name or os.path.basename(a.input_path), model_path=a.model_path,
                 solver_mode=a.solver_mode, steps=a.steps, guide_scale=a.cfg, upscale=a.upscale, max_chunk_len=a.max_chunk_len,
-                vae_path=a.vae_path, dtype=a.dtype, negative_embedding=a.negative_embedding)
+                vae_path=a.vae_path, dtype=a.dtype, negative_embedding=a.negative_embedding,
+                **({"text_state_dict": a.text_encoder_path} if a.text_encoder_path else {}))
     prompt = torch.load(a.prompt_embedding) if a.prompt_embedding else a.prompt
     print("saved", star.enhance_a_video(a.input_path, prompt))
 
