@@ -97,13 +97,15 @@ static int launch_tattn(Ctx* ctx, const TAttnArgs& a) {
   const long long items = (long long)a.HW * a.heads;
   const unsigned grid = (unsigned)((items + 3) / 4);
   if (a.F <= 32) STAR_LAUNCH((temporal_attn_kernel<T, 1>), dim3(grid), dim3(256), (size_t)(4 * 4096), ctx->stream, p);
-  else STAR_LAUNCH((temporal_attn_kernel<T, 2>), dim3(grid), dim3(256), (size_t)(4 * 8192), ctx->stream, p);
+  else if (a.F <= 64) STAR_LAUNCH((temporal_attn_kernel<T, 2>), dim3(grid), dim3(256), (size_t)(4 * 8192), ctx->stream, p);
+  else if (a.F <= 96) STAR_LAUNCH((temporal_attn_kernel<T, 3>), dim3(grid), dim3(256), (size_t)(4 * 12288), ctx->stream, p);
+  else STAR_LAUNCH((temporal_attn_kernel<T, 4>), dim3(grid), dim3(256), (size_t)(4 * 16384), ctx->stream, p);
   return 0;
 }
 
 int op_temporal_attn(Ctx* ctx, const TAttnArgs& a) {
   if (a.F <= 0 || a.HW <= 0) return 0;
-  if (a.F > 64) return ctx->fail("temporal_attn: at most 64 frames per chunk");
+  if (a.F > 128) return ctx->fail("temporal_attn: at most 128 frames per chunk");
   if ((a.ldq | a.ldk | a.ldv | a.ldo) & 7) return ctx->fail("temporal_attn: row strides must be multiples of 8 elements");
   ProfScope ps(ctx, PK_TATTN, 4.0 * a.HW * a.heads * (double)a.F * a.F * 64.0, 2.0 * 4.0 * a.F * (double)a.HW * a.heads * 64.0);
   if (ctx->dtype == DT_F16) return launch_tattn<f16>(ctx, a);

@@ -689,7 +689,8 @@ struct TAttnParams {
   float scale_log2e;
 };
 
-// one wavefront per (pixel, head); NB = number of 32-frame blocks (1: F<=32, 2: F<=64)
+// one wavefront per (pixel, head); NB = number of 32-frame blocks (F <= 32 NB; NB = 3 / 4, one wave per SIMD with the whole
+// 512-entry register file, cover the 65-128-frame chunks the reference's make_chunks can produce with --max_chunk_len 64)
 template <class T, int NB>
 STAR_GLOBAL void STAR_LAUNCH_BOUNDS(256)
 temporal_attn_kernel(const TAttnParams p) {

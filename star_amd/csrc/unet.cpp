@@ -394,7 +394,7 @@ int unet_forward_n(Ctx* ctx, const float* xt, long long t, const float* const* y
   if (nb < 1 || nb > 2) return ctx->fail("unet_forward: 1 or 2 guidance branches");
   const UNetModel& M = *ctx->unet;
   const UNetCfg& cfg = M.cfg;
-  if (F < 1 || F > 64) return ctx->fail("unet_forward: 1..64 frames per chunk");
+  if (F < 1 || F > 128) return ctx->fail("unet_forward: 1..128 frames per chunk");
   {  // legal latent sizes: every Downsample/Upsample pair must round-trip (H = 2 mod 8, W = 0 mod 8 for 3 levels)
     int h = H, w = W;
     for (int i = 0; i < cfg.n_levels - 1; ++i) { if (w % 2) return ctx->fail("unet_forward: illegal latent width"); h = h / 2 + 1; w /= 2; }

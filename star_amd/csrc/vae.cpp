@@ -12,6 +12,7 @@
 // all H*W tokens) is run unfused -- fp32 logits [N, N] materialised in HBM (1.4-2.8 GB at 122x216: sized for
 // 288 GB), row softmax, then P V -- on the same MFMA GEMM kernel.
 #include "vae.h"
+#include <cstdlib>
 
 namespace star {
 
@@ -102,7 +103,10 @@ struct VRun : Runner {
     g.epi = EPI_BIAS | (res ? EPI_RES : 0);
     ok(op_gemm(ctx, g));
   }
-  // Attention(heads = 1, dim_head = C, residual_connection, GroupNorm eps 1e-6), per frame, unfused
+  // Attention(heads = 1, dim_head = C = 512, residual_connection, GroupNorm eps 1e-6), per frame.  One head of width 512 does not
+  // fit the d = 64 flash kernel (the output tile alone would be 512 accumulators per lane), so the logits go through HBM -- but
+  // only a bounded block of query rows at a time (<= 2 GiB of fp32 logits + 16-bit probabilities), so that the 133 712-token
+  // frames of the 2160p configuration need 2 GiB of scratch instead of 107 GB.  It is 0.3 % of a clip's time.
   Act attn(const AttnVW& a, Act x) {
     const int C = a.C, HW = x.H * x.W;
     const int Np = (HW + 63) & ~63;
@@ -111,7 +115,12 @@ struct VRun : Runner {
     Act q = make(C, x.H, x.W), k = make(C, x.H, x.W), o = make(C, x.H, x.W);
     gemm(n.p(), C, rows(x), a.q, q.p(), C);
     gemm(n.p(), C, rows(x), a.k, k.p(), C);
-    Buf vt(ctx, (size_t)C * Np * es), S(ctx, (size_t)HW * Np * 4), P(ctx, (size_t)HW * Np * es);
+    long long qc = ((long long)1 << 31) / ((long long)Np * (4 + (long long)es));   // query rows per block
+    if (const char* e = getenv("STAR_VAE_ATTN_ROWS")) qc = atoll(e);   // tests: force several query blocks on a small frame
+    qc = (qc / 256) * 256;
+    if (qc < 256) qc = 256;
+    if (qc > HW) qc = HW;
+    Buf vt(ctx, (size_t)C * Np * es), S(ctx, (size_t)qc * Np * 4), P(ctx, (size_t)qc * Np * es);
     if (!vt.p || !S.p || !P.p) { rc = ctx->fail("out of device memory (VAE attention)"); return x; }
     const float scale = 1.0f / sqrtf((float)C);
     for (int f = 0; f < F; ++f) {
@@ -121,16 +130,19 @@ struct VRun : Runner {
         GemmArgs g; g.A = a.v_as_a.w.p; g.W = nf; g.C = vt.p; g.M = C; g.N = HW; g.K = C; g.lda = C; g.ldc = Np;
         ok(op_gemm(ctx, g));
       }
-      {  // S = Q K^T (fp32)
-        GemmArgs g; g.A = (const char*)q.p() + (size_t)f * HW * C * es; g.W = (const char*)k.p() + (size_t)f * HW * C * es;
-        g.C = S.p; g.M = HW; g.N = HW; g.K = C; g.lda = C; g.ldc = Np; g.epi = EPI_OUT_F32;
-        ok(op_gemm(ctx, g));
-      }
-      ok(op_softmax_rows(ctx, S.as<float>(), Np, P.p, Np, HW, HW, scale));
-      {  // O = P V + bv
-        GemmArgs g; g.A = P.p; g.W = vt.p; g.C = (char*)o.p() + (size_t)f * HW * C * es; g.M = HW; g.N = C; g.K = Np; g.lda = Np; g.ldc = C;
-        g.bias = (const float*)a.bv.p; g.epi = EPI_BIAS;
-        ok(op_gemm(ctx, g));
+      for (long long q0 = 0; q0 < HW; q0 += qc) {
+        const int nq = (int)((HW - q0 < qc) ? HW - q0 : qc);
+        {  // S = Q[q0 : q0 + nq] K^T (fp32)
+          GemmArgs g; g.A = (const char*)q.p() + ((size_t)f * HW + q0) * C * es; g.W = (const char*)k.p() + (size_t)f * HW * C * es;
+          g.C = S.p; g.M = nq; g.N = HW; g.K = C; g.lda = C; g.ldc = Np; g.epi = EPI_OUT_F32;
+          ok(op_gemm(ctx, g));
+        }
+        ok(op_softmax_rows(ctx, S.as<float>(), Np, P.p, Np, nq, HW, scale));
+        {  // O[q0 : q0 + nq] = P V + bv
+          GemmArgs g; g.A = P.p; g.W = vt.p; g.C = (char*)o.p() + ((size_t)f * HW + q0) * C * es; g.M = nq; g.N = C; g.K = Np; g.lda = Np; g.ldc = C;
+          g.bias = (const float*)a.bv.p; g.epi = EPI_BIAS;
+          ok(op_gemm(ctx, g));
+        }
       }
     }
     Act y = make(C, x.H, x.W);

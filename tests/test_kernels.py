@@ -343,7 +343,7 @@ def test_flash_attention_growing_max(ctx, dtype, variant):
     assert_close(out, ref_attention(q, k, v, heads), dtype, scale=6.0, what=f"flash growing max v{variant}")
 
 
-@pytest.mark.parametrize("Fr,HW,heads", [(5, 7, 2), (32, 9, 1), (40, 5, 2), (16, 130, 5), (1, 4, 1)])
+@pytest.mark.parametrize("Fr,HW,heads", [(5, 7, 2), (32, 9, 1), (40, 5, 2), (16, 130, 5), (1, 4, 1), (64, 3, 1), (80, 5, 2), (97, 3, 1), (128, 2, 1)])
 def test_temporal_attention(ctx, dtype, Fr, HW, heads):
     """attention over frames per pixel (unet_v2v.py:483-489), tokens stay in [F*HW, C] order."""
     g = torch.Generator().manual_seed(Fr * 31 + HW)

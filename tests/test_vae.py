@@ -68,3 +68,20 @@ def test_full_width_vae_small_image():
     z = torch.randn(3, 4, 8, 12, generator=g)
     out = vae.decode(z.cuda(), num_frames=3).sample
     assert rel_rms(out, VO.decode(sd, cfg, z, 3)) < REL[torch.float16]
+
+
+def test_mid_block_attention_in_query_blocks(backend, request, monkeypatch):
+    """the mid-block attention materialises its logits for a bounded block of query rows at a time (2 GiB at real sizes, so
+    that 133 712-token frames fit); forced to 256-row blocks here, the result must not change."""
+    emu = request.getfixturevalue("emu_lib") if backend == "emu" else None
+    cfg = SMALL_VAE_CONFIG
+    sd = random_vae_state_dict(cfg, seed=0)
+    g = torch.Generator().manual_seed(4)
+    H, W = (128, 192) if backend == "emu" else (192, 256)      # latent 16 x 24 = 384 / 24 x 32 = 768 tokens: 2 / 3 blocks of 256
+    x = torch.randn(1, 3, H, W, generator=g).clamp(-1, 1)
+    vae = AutoencoderKLTemporalDecoder(cfg, dtype=torch.float16, library=emu).load_state_dict(sd)
+    whole = vae.encode(x.to(vae.ctx.torch_device)).latent_dist.parameters.cpu()
+    monkeypatch.setenv("STAR_VAE_ATTN_ROWS", "256")
+    blocked = vae.encode(x.to(vae.ctx.torch_device)).latent_dist.parameters.cpu()
+    assert torch.equal(whole, blocked)
+    assert rel_rms(whole, VO.encode_moments(sd, cfg, x)) < REL[torch.float16]
