@@ -2,10 +2,14 @@
 
   python bench.py [--gpus N] [--steps K] [--warmup W]           (N > 1: launched by torch.distributed.run)
 
+  python bench.py --config cfg1|cfg2|cfg3|cfg4 ...               (other BASELINE configs; the default line is cfg2)
+
 One "step" = one full `VideoToVideo_sr.test()` on a synthetic 32-frame 240x426 clip -> 4x (BASELINE config[1]):
 bilinear upsample + pad to 976x1728, VAE encode of 32 frames, 50 DPM-Solver++ evaluations x 2 denoiser forwards
 (CFG), VAE decode in 3-frame groups; the LR clip is already resident in HBM when the timed region starts.
 N GPUs = N independent clips, one per rank (weak scaling), with an RCCL all-gather of the decoded frames (C1).
+--config cfg3 (72 frames as 8 overlapping 16-frame chunks) shards ONE video over the ranks instead: every solver step's
+chunks by ChunkSharder (all-gather of the x0 cores, C2), the VAE decode groups by FrameSharder (strong scaling).
 Random-init weights of the full architecture (2.04 B-parameter UNet+ControlNet, 97.7 M-parameter SVD VAE) and
 synthetic data: no checkpoint or dataset is reachable offline.
 
@@ -29,6 +33,15 @@ UNET_FWD_TFLOP_CFG2 = 572.3         # one UNet+ControlNet forward, 32 f, latent 
 VAE_TFLOP_PER_FRAME = 8.4 + 20.8    # encode + decode at 976x1728 (estimate)
 PEAK_BF16_MFMA = 2.5e15             # dense, MI355X_MICROARCH.md
 
+# BASELINE.json configs[0..3] (configs[4], CogVideoX, is out of scope: SURVEY.md section 8f).  fwd_tflop = one UNet+ControlNet
+# forward on one chunk (FlopCounterMode on the reference); vae_scale = padded pixels / (976*1728).
+CONFIGS = {
+    "cfg1": dict(frames=8, height=128, width=128, denoise_steps=5, solver_mode="normal", max_chunk_len=32, fwd_tflop=64.4, chunks=1, vae_scale=720 * 1280 / (976 * 1728)),
+    "cfg2": dict(frames=32, height=240, width=426, denoise_steps=50, solver_mode="normal", max_chunk_len=32, fwd_tflop=572.3, chunks=1, vae_scale=1.0),
+    "cfg3": dict(frames=72, height=240, width=426, denoise_steps=50, solver_mode="fast", max_chunk_len=16, fwd_tflop=286.2, chunks=8, vae_scale=1.0),
+    "cfg4": dict(frames=32, height=540, width=960, denoise_steps=50, solver_mode="normal", max_chunk_len=32, fwd_tflop=7582.0, chunks=1, vae_scale=2192 * 3904 / (976 * 1728)),
+}
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -37,16 +50,27 @@ def main():
     ap.add_argument("--warmup", type=int, default=0)
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"],
                     help="storage/MFMA input type; f16 = the reference's own (generator.half()+autocast) and the one that meets the PSNR>=50 dB parity bar")
-    ap.add_argument("--frames", type=int, default=32)
-    ap.add_argument("--height", type=int, default=240)
-    ap.add_argument("--width", type=int, default=426)
-    ap.add_argument("--denoise-steps", type=int, default=50)
-    ap.add_argument("--solver-mode", default="normal", choices=["normal", "fast"])
+    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS), help="BASELINE.json configs[0..3]; cfg2 is the metric's configuration")
+    ap.add_argument("--frames", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--denoise-steps", type=int, default=None)
+    ap.add_argument("--solver-mode", default=None, choices=["normal", "fast"])
+    ap.add_argument("--max-chunk-len", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--small", action="store_true", help="reduced-width smoke configuration (NOT the metric)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl = RCCL over xGMI (default); gloo only for single-GPU plumbing tests")
     ap.add_argument("--share-gpu0", action="store_true", help="TEST ONLY: every rank uses cuda:0 (1-GPU box, gloo backend)")
     args = ap.parse_args()
+    cfg = dict(CONFIGS[args.config])
+    custom = False
+    for k in ("frames", "height", "width", "denoise_steps", "solver_mode", "max_chunk_len"):
+        v = getattr(args, k)
+        if v is None:
+            setattr(args, k, cfg[k])
+        elif v != cfg[k]:
+            custom = True
+    shard_one_video = args.config == "cfg3"
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -83,22 +107,27 @@ def main():
     gneg = torch.Generator().manual_seed(668)
     opt = dict(state_dict=sd, vae_state_dict=random_vae_state_dict(vcfg, seed=0), unet_config=ucfg, vae_config=vcfg, dtype=dtype,
                negative_y=torch.randn(1, 77, ucfg.context_dim, generator=gneg))
+    if shard_one_video and world > 1:       # one long video: identical noise on every rank, chunks / decode groups sharded
+        from star_amd.parallel import ChunkSharder, FrameSharder
+        opt.update(rng=torch.Generator().manual_seed(666), chunk_executor=ChunkSharder(), frame_sharder=FrameSharder())
     t0 = time.time()
     model = VideoToVideo_sr(opt, device=dev)
     del sd, opt
     t_load = time.time() - t0
 
     # synthetic LR clip + text embedding (seeds: SURVEY.md section 8d), resident on the device
-    g = torch.Generator().manual_seed(666 + rank)
+    g = torch.Generator().manual_seed(666 + (0 if shard_one_video else rank))
     video = (torch.randn(args.frames, 3, args.height, args.width, generator=g) * 0.5).clamp(-1, 1).to(dev)
     y = torch.randn(1, 77, ucfg.context_dim, generator=torch.Generator().manual_seed(667)).to(dev)
     data = {"video_data": video, "y": y, "target_res": (args.height * 4, args.width * 4)}
 
     def step():
         torch.manual_seed(666 + rank)
+        if model.rng is not None:
+            model.rng.manual_seed(666)
         out = model.test(data, total_noise_levels=900, steps=args.denoise_steps, solver_mode=args.solver_mode,
-                         guide_scale=7.5, max_chunk_len=max(32, args.frames), return_device=True)
-        if world > 1:
+                         guide_scale=7.5, max_chunk_len=args.max_chunk_len, return_device=True)
+        if world > 1 and not shard_one_video:
             from star_amd.parallel import gather_frames
             out = gather_frames(out)
         return out
@@ -129,13 +158,13 @@ def main():
     finite = bool(torch.isfinite(final).all())
 
     if rank == 0:
-        frames_total = args.frames * world * args.steps
+        frames_total = args.frames * (1 if shard_one_video else world) * args.steps
         evals = 14 if args.solver_mode == "fast" else args.denoise_steps
         a = prof_u["attn_self"]
         l0_flops = a["max_flops"]                       # the largest launches = the L0 layers (N = H*W of the padded latent)
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r01_attn_traffic.json")
-        if os.path.isfile(tpath) and not args.small and args.frames == 32:   # PMC pass of the same kernel at the same shape
+        if os.path.isfile(tpath) and not args.small and args.config in ("cfg2", "cfg3") and not custom:   # PMC pass of the same kernel at the same shape
             traffic = json.load(open(tpath))["traffic_bytes_per_launch"]
         roof = {"bound": "mfma", "kernel": "flash_attn_v3_kernel (spatial self-attention, d=64)", "unit": "TFLOP/s",
                 "achieved": (l0_flops / (a["max_flops_ms"] * 1e-3) / 1e12) if a["max_flops_ms"] else None,
@@ -148,18 +177,24 @@ def main():
                          "TFLOP/s": round(v["flops"] / v["ms"] / 1e9, 1) if v["ms"] and v["flops"] else None,
                          "GB/s": round(v["bytes"] / v["ms"] / 1e6, 1) if v["ms"] else None} for k, v in prof_u.items()}
         line = {
-            "metric": "upscaled frames/sec (4x, 32f 240x426 chunk)", "value": frames_total / elapsed, "unit": "frames/s",
+            "metric": "upscaled frames/sec (4x, 32f 240x426 chunk)" if args.config == "cfg2" and not custom else
+                      f"upscaled frames/sec (4x, {args.frames}f {args.height}x{args.width}; BASELINE {args.config}{' modified' if custom else ''})",
+            "value": frames_total / elapsed, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"I2VGen-XL STAR light_deg path, {args.frames}f {args.height}x{args.width} -> 4x "
+            "higher_is_better": True, "scaling": "strong" if shard_one_video else "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"baseline_config": args.config + (" (modified)" if custom else ""),
+                       "workload": f"I2VGen-XL STAR path, {args.frames}f {args.height}x{args.width} -> 4x "
                                    f"({args.height * 4}x{args.width * 4}, padded latent), solver_mode={args.solver_mode}, "
                                    f"{evals} DPM++(2M)SDE evals x 2 CFG forwards, VAE enc 1f/call + dec 3f/group, "
                                    "random-init weights" + (" [REDUCED-WIDTH SMOKE CONFIG]" if args.small else ""),
-                       "frames_per_gpu": args.frames, "evals": evals, "parallelism": f"chunk-replicas x{world} + RCCL all-gather of frames"},
+                       "frames_per_gpu": args.frames, "evals": evals, "max_chunk_len": args.max_chunk_len,
+                       "parallelism": (f"one video, solver-step chunks + VAE groups sharded over {world} ranks (RCCL all-gather of x0 cores / frames)"
+                                       if shard_one_video else f"chunk-replicas x{world} + RCCL all-gather of frames")},
             "roofline": roof, "cpu_baseline": cpu_baseline,
             "unet_kernel_ms": breakdown, "vae_kernel_ms": {k: round(v["ms"], 1) for k, v in prof_v.items()},
             "setup_s": {"weights": round(t_weights, 1), "load": round(t_load, 1)},
-            "algorithmic_pflop_per_step": (2 * evals * UNET_FWD_TFLOP_CFG2 + args.frames * VAE_TFLOP_PER_FRAME) / 1e3 if not args.small else None,
+            "algorithmic_pflop_per_step": (2 * evals * cfg["chunks"] * cfg["fwd_tflop"] + args.frames * VAE_TFLOP_PER_FRAME * cfg["vae_scale"]) / 1e3
+                                          if not args.small and not custom else None,
             "output_finite": finite, "hbm_pool_gb": {"unet": round(uctx.lib.pool_peak_bytes(uctx.h) / 2 ** 30, 1), "vae": round(vctx.lib.pool_peak_bytes(vctx.h) / 2 ** 30, 1)},
         }
         print(json.dumps(line), flush=True)
@@ -169,33 +204,49 @@ def main():
 
 
 def run_cpu_baseline(sd, ucfg, args):
-    """Time the CPU oracle (oracle/unet_oracle.py: a PyTorch fp32 port of the reference forward) on all host cores on a
-    bounded sample -- one UNet+ControlNet forward at f=8, latent 26x24 -- and extrapolate to the benchmark workload by
-    the FLOP ratio (the full workload is ~58 PFLOP: tens of hours on a CPU)."""
+    """Time the CPU oracle (oracle/unet_oracle.py: a PyTorch fp32 port of the reference forward, pinned to the reference's own
+    code by tests/test_oracle.py; /root/reference itself does not exist on the GPU box) on this box's host cores:
+      1. a quick thread sweep on a small forward picks the thread count (torch's CPU kernels collapse on these shapes when
+         given all 256 hardware threads), and
+      2. ONE full UNet+ControlNet forward at the real level-0 shape of BASELINE config[0] (latent 90x160 = 14 400 tokens per
+         frame, full 2.04 B-parameter width) on 4 frames is the measured sample (tens of TFLOP, tens of seconds).
+    The frames/s figure is that measured rate EXTRAPOLATED by FLOP ratio to the benchmark workload and says so; the
+    workload itself is tens of PFLOP -- days on a CPU."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import unet_oracle as O
     from make_golden import unet_inputs
     from torch.utils.flop_counter import FlopCounterMode
-    # torch's CPU kernels stop scaling (and collapse) far below this box's hardware thread count on these small
-    # tensors: 256 threads ran the same sample at 5 GFLOP/s vs ~400 GFLOP/s on 8; use a bounded, stated thread count
-    cores = min(32, os.cpu_count() or 1)
+    ncpu = os.cpu_count() or 1
+    small = args.small
+
+    def timed(f, h, w, seed):
+        x, t, y, hint = unet_inputs(ucfg, f, h, w, seed)
+        with FlopCounterMode(display=False) as fc:
+            t0 = time.perf_counter()
+            O.unet_forward(sd, ucfg, x, t, y, hint)
+            secs = time.perf_counter() - t0
+        return float(fc.get_total_flops()), secs
+
+    sweep = {}
+    for n in [c for c in (8, 16, 32, 64, 128) if c <= ncpu] or [ncpu]:
+        torch.set_num_threads(n)
+        timed(1, 10, 8, 3)                                   # warm the pool at this size
+        fl, secs = timed(2, 26, 24, 5)
+        sweep[n] = fl / secs / 1e9
+    cores = max(sweep, key=sweep.get)
     torch.set_num_threads(cores)
-    f, h, w = 8, 26, 24
-    x, t, y, hint = unet_inputs(ucfg, f, h, w, 7)
-    O.unet_forward(sd, ucfg, x[:, :, :1, :10, :8].contiguous(), t, y, hint[:, :, :1, :10, :8].contiguous())   # warm the thread pools
-    with FlopCounterMode(display=False) as fc:
-        t0 = time.perf_counter()
-        O.unet_forward(sd, ucfg, x, t, y, hint)
-        secs = time.perf_counter() - t0
-    flops = float(fc.get_total_flops())
+    f, h, w = (2, 26, 24) if small else (4, 90, 160)
+    flops, secs = timed(f, h, w, 7)
     cpu_flops = flops / secs
     evals = 14 if args.solver_mode == "fast" else args.denoise_steps
-    total = (2 * evals * UNET_FWD_TFLOP_CFG2 + args.frames * VAE_TFLOP_PER_FRAME) * 1e12
+    cfg = CONFIGS[args.config]
+    total = (2 * evals * cfg["chunks"] * cfg["fwd_tflop"] + args.frames * VAE_TFLOP_PER_FRAME * cfg["vae_scale"]) * 1e12
     return {"value": args.frames / (total / cpu_flops), "unit": "frames/s", "cores": cores, "kind": "port",
-            "host_threads_available": os.cpu_count(),
-            "sample": f"one UNet+ControlNet forward of the fp32 CPU oracle at f={f}, latent {h}x{w} ({flops / 1e12:.2f} TFLOP in {secs:.1f} s = "
-                      f"{cpu_flops / 1e9:.0f} GFLOP/s); frames/s EXTRAPOLATED by FLOP ratio to the {total / 1e15:.1f} PFLOP workload",
-            "measured_gflops": cpu_flops / 1e9, "sample_seconds": secs}
+            "host_threads_available": ncpu, "thread_sweep_gflops": {str(k): round(v, 1) for k, v in sweep.items()},
+            "sample": f"one full-width UNet+ControlNet forward of the fp32 CPU oracle at f={f}, latent {h}x{w} (the level-0 shape of BASELINE "
+                      f"config[0]): {flops / 1e12:.1f} TFLOP in {secs:.1f} s = {cpu_flops / 1e9:.0f} GFLOP/s on {cores} threads (best of the sweep); "
+                      f"frames/s EXTRAPOLATED by FLOP ratio to the {total / 1e15:.1f} PFLOP workload (= {total / cpu_flops / 3600:.1f} h on this host)",
+            "measured_gflops": cpu_flops / 1e9, "sample_seconds": secs, "sample_tflop": flops / 1e12}
 
 
 if __name__ == "__main__":

@@ -143,7 +143,7 @@ class GaussianDiffusion:
                 return x0c[:, :, a:b]
 
             if chunk_executor is not None:
-                cores = chunk_executor(run_chunk, len(chunk_inds))
+                cores = chunk_executor(run_chunk, len(chunk_inds), key=(tuple(xt.shape), tuple(map(tuple, chunk_inds))))
             else:
                 cores = [run_chunk(i) for i in range(len(chunk_inds))]
             return torch.concat(cores, dim=2)

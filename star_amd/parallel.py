@@ -8,7 +8,8 @@ The path shards along the frame-chunk axis:
     337-350), so `ChunkSharder` gives chunk i to rank i % world and all-gathers the trimmed x0 cores (C2, a few MB)
     so that every rank applies the identical solver update to the full-length latent.  VAE decode groups of 3 frames
     are sharded the same way by `FrameSharder`.
-No reduce-type collective exists anywhere on the path.
+The only collectives are all-gathers: the payload (RCCL over xGMI) and, once per (latent shape, chunk list), two small
+all-gathers of part counts / sizes; no reduce-type collective exists anywhere on the path.
 """
 import torch
 import torch.distributed as dist
@@ -18,37 +19,61 @@ def _world(group):
     return dist.get_world_size(group), dist.get_rank(group)
 
 
-def _all_gather_ragged(parts, dim, group):
+_DTYPES = [torch.float32, torch.float16, torch.bfloat16, torch.float64]
+
+
+def _gather_ints(vec, group, device):
+    """all-gather of a small int64 vector (metadata only; runs once per plan, see _RaggedPlan)."""
+    world, _ = _world(group)
+    v = vec.to(device)
+    outs = [torch.empty_like(v) for _ in range(world)]
+    dist.all_gather(outs, v, group=group)
+    return torch.stack(outs).cpu()
+
+
+class _RaggedPlan:
+    """Who sends how many parts of which size: static for a given (latent shape, chunk list) / (frame count, groups), so it
+    is exchanged ONCE (two small all-gathers, no reduce, no pickling, any number of parts) and cached under a key every rank
+    computes identically; every later call is a single RCCL all-gather of the payload."""
+
+    def __init__(self, parts, dim, group, device):
+        world, rank = _world(group)
+        head = torch.zeros(12, dtype=torch.int64)
+        head[0] = len(parts)
+        if parts:
+            ref = parts[0]
+            assert ref.dim() <= 8
+            head[1], head[2] = ref.dim(), _DTYPES.index(ref.dtype)
+            head[3:3 + ref.dim()] = torch.tensor(ref.shape)
+        heads = _gather_ints(head, group, device)
+        nmax = max(1, int(heads[:, 0].max()))
+        mine = torch.zeros(nmax, dtype=torch.int64)
+        for j, q in enumerate(parts):
+            mine[j] = q.shape[dim]
+        sizes = _gather_ints(mine, group, device)
+        self.sizes = [[int(sizes[r, j]) for j in range(int(heads[r, 0]))] for r in range(world)]
+        owner = next(r for r in range(world) if int(heads[r, 0]) > 0)
+        nd = int(heads[owner, 1])
+        self.dtype = _DTYPES[int(heads[owner, 2])]
+        self.pad_shape = [int(v) for v in heads[owner, 3:3 + nd]]
+        self.pad_shape[dim] = max(sum(sz) for sz in self.sizes)
+        self.own = [q.shape[dim] for q in parts]
+
+
+def _all_gather_ragged(parts, dim, group, cache=None, key=None):
     """all-gather per-rank lists of tensors whose sizes differ along `dim` -> list (per rank) of lists of tensors."""
     world, rank = _world(group)
-    device = parts[0].device if parts else None
-    counts = torch.zeros(world, 64, dtype=torch.int64)
-    assert len(parts) <= 63
-    counts[rank, 0] = len(parts)
-    for j, p in enumerate(parts):
-        counts[rank, 1 + j] = p.shape[dim]
-    cdev = counts.to(device) if device is not None and device.type == "cuda" else counts
-    dist.all_reduce(cdev, group=group)          # tiny metadata exchange (sizes only)
-    counts = cdev.cpu()
-    total = counts[:, 1:].sum(dim=1)
-    mx = int(total.max())
-    ref = None
-    for p in parts:
-        ref = p
-    # every rank needs a template for shape/dtype even if it owns no part
-    meta = [None]
-    if ref is not None:
-        shp = list(ref.shape)
-        shp[dim] = 0
-        meta = [(shp, ref.dtype)]
-    gathered_meta = [None] * world
-    dist.all_gather_object(gathered_meta, meta[0], group=group)
-    shp, dtype = next(m for m in gathered_meta if m is not None)
-    if device is None:
+    if parts:
+        device = parts[0].device
+    else:
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
-    pad_shape = list(shp)
-    pad_shape[dim] = mx
-    buf = torch.zeros(pad_shape, dtype=dtype, device=device)
+    plan = cache.get(key) if cache is not None and key is not None else None
+    if plan is None:
+        plan = _RaggedPlan(parts, dim, group, device)
+        if cache is not None and key is not None:
+            cache[key] = plan
+    assert plan.own == [q.shape[dim] for q in parts], "ragged-gather plan does not match this call (key collision)"
+    buf = torch.zeros(plan.pad_shape, dtype=plan.dtype, device=device)
     if parts:
         cat = torch.cat(parts, dim=dim)
         buf.narrow(dim, 0, cat.shape[dim]).copy_(cat)
@@ -56,12 +81,10 @@ def _all_gather_ragged(parts, dim, group):
     dist.all_gather(outs, buf, group=group)      # RCCL all-gather over xGMI (C1 / C2)
     result = []
     for r in range(world):
-        n = int(counts[r, 0])
-        sizes = [int(counts[r, 1 + j]) for j in range(n)]
         off, lst = 0, []
-        for s in sizes:
-            lst.append(outs[r].narrow(dim, off, s))
-            off += s
+        for sz in plan.sizes[r]:
+            lst.append(outs[r].narrow(dim, off, sz))
+            off += sz
         result.append(lst)
     return result
 
@@ -71,11 +94,14 @@ class ChunkSharder:
 
     def __init__(self, group=None):
         self.group = group
+        self._plans = {}
 
-    def __call__(self, run_chunk, n_chunks):
+    def __call__(self, run_chunk, n_chunks, key=None):
+        """key: anything every rank computes identically and that fixes the part sizes (sample_sr passes the latent shape and
+        the chunk list); the size exchange then happens in the first solver step only."""
         world, rank = _world(self.group)
         mine = [run_chunk(i) for i in range(rank, n_chunks, world)]
-        per_rank = _all_gather_ragged(mine, dim=2, group=self.group)
+        per_rank = _all_gather_ragged(mine, dim=2, group=self.group, cache=self._plans, key=key)
         cores = [None] * n_chunks
         for r in range(world):
             for j, i in enumerate(range(r, n_chunks, world)):
@@ -92,7 +118,7 @@ class FrameSharder:
     def map_groups(self, groups, fn):
         world, rank = _world(self.group)
         mine = [fn(a, b) for (a, b) in groups[rank::world]]
-        per_rank = _all_gather_ragged(mine, dim=0, group=self.group)
+        per_rank = _all_gather_ragged(mine, dim=0, group=self.group)   # once per video: no plan cache needed
         out = [None] * len(groups)
         for r in range(world):
             for j, i in enumerate(range(r, len(groups), world)):

@@ -182,17 +182,27 @@ class VideoToVideo_sr:
         return torch.cat([self.temporal_vae_decode(z[a:b], b - a) for a, b in groups])
 
     def vae_encode(self, t, chunk_size=1):
-        """one frame per encoder pass; the posterior noise is drawn for ALL frames in frame order (:153-161)."""
+        """one frame per encoder pass; the posterior noise is drawn for ALL frames in frame order (:153-161).  With a
+        frame_sharder (and the shared CPU generator that makes every rank draw identical noise) each rank encodes only its
+        own frames and the latents are all-gathered."""
         num_f = t.shape[1]
         t = t.reshape(-1, *t.shape[2:])
-        z_list = []
-        for ind in range(0, t.shape[0], chunk_size):
-            dist_ = self.vae.encode(t[ind:ind + chunk_size]).latent_dist
-            if self.rng is not None:
-                eps = torch.randn(dist_.mean.shape, generator=self.rng, dtype=torch.float32).to(dist_.mean.device)
-                z_list.append(dist_.mean + dist_.std * eps)
-            else:
-                z_list.append(dist_.sample())
-        z = torch.cat(z_list, dim=0)
+        f = self.vae.cfg.downsample
+        lat_shape = (chunk_size, self.vae.cfg.latent_channels, t.shape[-2] // f, t.shape[-1] // f)
+        groups = [(i, min(i + chunk_size, t.shape[0])) for i in range(0, t.shape[0], chunk_size)]
+        eps = None
+        if self.rng is not None:
+            eps = [torch.randn((b - a,) + lat_shape[1:], generator=self.rng, dtype=torch.float32) for a, b in groups]
+
+        def enc(a, b):
+            dist_ = self.vae.encode(t[a:b]).latent_dist
+            if eps is None:
+                return dist_.sample()
+            return dist_.mean + dist_.std * eps[a // chunk_size].to(dist_.mean.device)
+
+        if self.frame_sharder is not None and eps is not None:
+            z = self.frame_sharder.map_groups(groups, enc)
+        else:
+            z = torch.cat([enc(a, b) for a, b in groups], dim=0)
         z = z.reshape(1, num_f, *z.shape[1:]).permute(0, 2, 1, 3, 4)
         return z * self.vae.config.scaling_factor

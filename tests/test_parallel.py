@@ -61,6 +61,9 @@ def _worker(rank, world, port, q):
         groups = [(i, min(i + 3, 11)) for i in range(0, 11, 3)]
         out = FrameSharder().map_groups(groups, lambda a, b: z[a:b] * 2)
         res["frames"] = bool(torch.equal(out, z * 2))
+        zl = torch.arange(400 * 2, dtype=torch.float32).reshape(400, 2)      # 134 groups -> 67 parts per rank (more than one metadata row held before)
+        gl = [(i, min(i + 3, 400)) for i in range(0, 400, 3)]
+        res["frames_many_groups"] = bool(torch.equal(FrameSharder().map_groups(gl, lambda a, b: zl[a:b] + 1), zl + 1))
         clip = torch.full((1, 3, 2, 4, 4), float(rank))
         allc = gather_frames(clip)
         res["gather"] = all(float(allc[r].mean()) == r for r in range(world))

@@ -1,0 +1,99 @@
+"""BASELINE.json's parity bar -- PSNR >= 50 dB against the reference CPU path on identical latents / noise -- at FULL WIDTH on
+BASELINE config[0]'s geometry (8 frames 128x128 -> x4, padded to 720x1280, latent 90x160, 5 solver steps).
+
+tests/golden/cfg1_full.pt was produced by oracle/make_golden_cfg1.py in the build container: the REFERENCE's own
+`ControlledV2VUNet` (2.04 B parameters) and `GaussianDiffusion.sample_sr` executed in fp32 on the CPU (40 minutes), the VAE by
+oracle/vae_oracle.py (parity unpinned: diffusers is absent).  Inputs and weights are re-derived here from the same seeds.
+"""
+import math
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+GOLD = os.path.join(ROOT, "tests", "golden", "cfg1_full.pt")
+torch.set_grad_enabled(False)
+
+
+def psnr(a, b, data_range):
+    mse = float((a.double() - b.double()).pow(2).mean())
+    return 10 * math.log10(data_range ** 2 / max(mse, 1e-30))
+
+
+def test_golden_fixture_is_consistent():
+    """CPU: the fixture matches the generator script's configuration and its tensors have the cfg1 shapes."""
+    from make_golden_cfg1 import CFG1, cfg1_inputs
+    g = torch.load(GOLD)
+    assert g["cfg"] == CFG1
+    assert tuple(g["z"].shape) == tuple(g["x0_final"].shape) == tuple(g["x0_first"].shape) == (1, 4, 8, 90, 160)
+    assert tuple(g["video_out_f16"].shape) == (1, 3, 8, 512, 512) and g["video_out_f16"].dtype == torch.float16
+    video, y, neg = cfg1_inputs()
+    assert video.shape == (8, 3, 128, 128) and float(video.abs().max()) <= 1.0
+    assert all(torch.isfinite(g[k].float()).all() for k in ("z", "noised", "x0_first", "x0_final", "video_out_f16"))
+
+
+@pytest.fixture(scope="module")
+def pipeline():
+    from make_golden_cfg1 import CFG1, cfg1_inputs
+    from star_amd.topology import UNetConfig, random_state_dict
+    from star_amd.vae_topology import VaeConfig, random_vae_state_dict
+    from star_amd.video_to_video_model import VideoToVideo_sr
+    video, y, neg = cfg1_inputs()
+    model = VideoToVideo_sr(dict(state_dict=random_state_dict(UNetConfig(), seed=CFG1["wseed"]),
+                                 vae_state_dict=random_vae_state_dict(VaeConfig(), seed=CFG1["wseed"]),
+                                 dtype=torch.float16, negative_y=neg, rng=torch.Generator().manual_seed(CFG1["rng_seed"])))
+    return model, video, y, neg, torch.load(GOLD), CFG1
+
+
+@pytest.mark.gpu
+def test_denoiser_on_identical_latents_matches_the_reference(pipeline):
+    """the chunk's whole sampling loop (10 full-width denoiser forwards, CFG + rescale, DPM++(2M) SDE) started from the golden
+    VAE latent and noised latent, with the same injected solver noise: latent-space PSNR and the first evaluation's x0."""
+    model, video, y, neg, gold, CFG1 = pipeline
+    dev = model._tensor_device
+    gen = torch.Generator().manual_seed(CFG1["rng_seed"])
+    for _ in range(CFG1["frames"]):                       # the generator's consumption order: posterior noise per frame,
+        torch.randn(1, 4, 90, 160, generator=gen)
+    torch.randn(gold["z"].shape, generator=gen)           # diffuse noise, then one tensor per solver step
+    z, noised = gold["z"].to(dev), gold["noised"].to(dev)
+
+    class Sampler:
+        def __init__(self, x, a, b, seed=None):
+            self.shape, self.device = x.shape, x.device
+
+        def __call__(self, s, sn):
+            return torch.randn(self.shape, generator=gen).to(self.device)
+
+    kw = [{"y": y.to(dev)}, {"y": neg.to(dev)}, {"hint": z}]
+    t = torch.LongTensor([CFG1["total_noise_levels"] - 1]).to(dev)
+    first = model.diffusion.denoise_x0(noised, t, model.generator, kw, CFG1["guide_scale"], 0.2).cpu()
+    rng1 = float(gold["x0_first"].max() - gold["x0_first"].min())
+    p1 = psnr(first, gold["x0_first"], rng1)
+    x0 = model.diffusion.sample_sr(noise=noised, model=model.generator, model_kwargs=kw, guide_scale=CFG1["guide_scale"], guide_rescale=0.2,
+                                   solver="dpmpp_2m_sde", solver_mode=CFG1["solver_mode"], steps=CFG1["steps"], t_max=CFG1["total_noise_levels"] - 1,
+                                   t_min=0, discretization="trailing", chunk_inds=None, noise_sampler_cls=Sampler).cpu()
+    rng = float(gold["x0_final"].max() - gold["x0_final"].min())
+    p = psnr(x0, gold["x0_final"], rng)
+    print(f"cfg1 full width, fp16: first-evaluation x0 PSNR {p1:.1f} dB, final latent PSNR {p:.1f} dB (ranges {rng1:.2f} / {rng:.2f})")
+    assert torch.isfinite(x0).all()
+    assert p1 >= 50.0 and p >= 50.0, (p1, p)
+
+
+@pytest.mark.gpu
+def test_whole_test_call_psnr_at_least_50_db(pipeline):
+    """`VideoToVideo_sr.test()` end to end (resize + pad, VAE encode, sampling, VAE decode, crop) against the decoded reference
+    output: the stated bar, asserted."""
+    model, video, y, neg, gold, CFG1 = pipeline
+    model.rng.manual_seed(CFG1["rng_seed"])
+    out = model.test({"video_data": video.to(model._tensor_device), "y": y, "target_res": CFG1["target"]},
+                     total_noise_levels=CFG1["total_noise_levels"], steps=CFG1["steps"], solver_mode=CFG1["solver_mode"],
+                     guide_scale=CFG1["guide_scale"], max_chunk_len=32)
+    ref = gold["video_out_f16"].float()
+    assert out.shape == ref.shape and out.dtype == torch.float32 and out.device.type == "cpu"
+    lo, hi = gold["out_range"]
+    p = psnr(out, ref, hi - lo)
+    print(f"cfg1 full width, fp16: decoded-output PSNR vs the reference CPU path {p:.1f} dB (range [{lo:.2f}, {hi:.2f}])")
+    assert torch.isfinite(out).all() and p >= 50.0, p

@@ -20,7 +20,7 @@ def psnr(a, b, data_range=2.0):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dtype,min_psnr", [(torch.float16, 45.0), (torch.bfloat16, 30.0)], ids=["f16", "bf16"])
+@pytest.mark.parametrize("dtype,min_psnr", [(torch.float16, 50.0), (torch.bfloat16, 30.0)], ids=["f16", "bf16"])   # f16 = the parity dtype (bar: 50 dB); bf16 is an opt-in speed mode that does not meet it
 def test_pipeline_psnr_vs_cpu_oracle(dtype, min_psnr):
     import pipeline_oracle as PO
     from star_amd.topology import SMALL_TEST_CONFIG, random_state_dict
@@ -44,3 +44,50 @@ def test_pipeline_psnr_vs_cpu_oracle(dtype, min_psnr):
     print(f"pipeline PSNR vs CPU oracle ({dtype}): {p:.1f} dB; ref range [{float(ref.min()):.2f}, {float(ref.max()):.2f}]")
     assert torch.isfinite(out).all()
     assert p >= min_psnr, p
+
+
+@pytest.mark.gpu
+def test_chunked_solver_loop_with_the_hip_denoiser():
+    """the per-step chunk loop (diffusion_sdedit.py:330-353: overlapping chunks, hint_chunk slices, overlap trim, concat) driven
+    with the HIP denoiser on the GPU against the same loop with the CPU oracle denoiser: 41 frames -> chunks (0,32), (16,41)."""
+    import unet_oracle as O
+    from star_amd.diffusion import GaussianDiffusion, noise_schedule
+    from star_amd.geometry import make_chunks
+    from star_amd.modules.unet_v2v import ControlledV2VUNet
+    from star_amd.topology import SMALL_TEST_CONFIG, random_state_dict
+    cfg = SMALL_TEST_CONFIG
+    sd = random_state_dict(cfg, seed=0)
+    net = ControlledV2VUNet(cfg, dtype=torch.float16, device=0)
+    net.load_state_dict(sd)
+    g = torch.Generator().manual_seed(12)
+    F_, h, w = 41, 18, 16
+    noise = torch.randn(1, 4, F_, h, w, generator=g)
+    hint = torch.randn(1, 4, F_, h, w, generator=g) * 0.5
+    y, neg = torch.randn(1, 77, cfg.context_dim, generator=g), torch.randn(1, 77, cfg.context_dim, generator=g)
+    chunks = make_chunks(F_, 0, 32)
+    assert chunks == [(0, 32), (16, 41)]
+    gd = GaussianDiffusion(noise_schedule(schedule="logsnr_cosine_interp", n=1000, zero_terminal_snr=True, scale_min=2.0, scale_max=4.0))
+
+    def run(model, dev):
+        gen = torch.Generator().manual_seed(3)
+
+        class Sampler:
+            def __init__(self, x, a, b, seed=None):
+                self.shape = x.shape
+
+            def __call__(self, s, sn):
+                return torch.randn(self.shape, generator=gen).to(dev)
+
+        return gd.sample_sr(noise=noise.to(dev), model=model, model_kwargs=[{"y": y.to(dev)}, {"y": neg.to(dev)}, {"hint": hint.to(dev)}],
+                            guide_scale=7.5, guide_rescale=0.2, solver="dpmpp_2m_sde", solver_mode="normal", steps=3, t_max=899, t_min=0,
+                            discretization="trailing", chunk_inds=chunks, noise_sampler_cls=Sampler).cpu()
+
+    def oracle(x, t=None, y=None, hint=None, hint_chunk=None, variant_info=None):
+        return O.unet_forward(sd, cfg, x, t, y, hint_chunk if hint_chunk is not None else hint)
+
+    out = run(net, torch.device("cuda", 0))
+    ref = run(oracle, torch.device("cpu"))
+    p = psnr(out, ref, data_range=float(ref.max() - ref.min()))
+    print(f"chunked loop, HIP denoiser vs CPU oracle: latent PSNR {p:.1f} dB")
+    assert out.shape == ref.shape == (1, 4, F_, h, w) and torch.isfinite(out).all()
+    assert p >= 50.0, p
