@@ -43,6 +43,9 @@ int star_sync(star_ctx* ctx);
 int star_is_hostemu(void);                               /* 1 only in the test-tooling emulator build */
 int star_has_bench_variants(void);                       /* 1 only in builds with -DSTAR_BENCH_VARIANTS (tools/bench, emulator): losing A/B
                                                             kernels and timing ablations; the product library answers 0 and rejects their ids */
+/* replaces: torch.cuda.empty_cache() at the phase boundaries of test() (video_to_video_model.py:94,106,127): synchronises the
+ * context's stream and returns its cached free blocks to the driver (the UNet and the VAE context each keep their own arena) */
+int star_pool_trim(star_ctx* ctx);
 size_t star_pool_bytes(star_ctx* ctx);
 size_t star_pool_peak_bytes(star_ctx* ctx);
 

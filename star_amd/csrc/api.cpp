@@ -87,6 +87,13 @@ int star_sync(star_ctx* h) {
   if (rt::stream_sync(h->c.stream)) return h->c.fail(std::string("sync failed: ") + rt::last_error_string());
   return 0;
 }
+int star_pool_trim(star_ctx* h) {   // return the cached (free) blocks to the driver: phase boundaries of test(), where the reference calls empty_cache()
+  if (!h) return 1;
+  rt::set_device(h->c.device);
+  if (rt::stream_sync(h->c.stream)) return h->c.fail(std::string("pool_trim: sync failed: ") + rt::last_error_string());
+  h->c.pool.trim();
+  return 0;
+}
 size_t star_pool_bytes(star_ctx* h) { return h->c.pool.total(); }
 size_t star_pool_peak_bytes(star_ctx* h) { return h->c.pool.peak(); }
 

@@ -469,6 +469,7 @@ void rt_note_launch_error(const char* what);
         star_attr_set_ = (size_t)(smem);                                                                \
       }                                                                                                 \
     }                                                                                                   \
+    (void)hipGetLastError();   /* a stale error of an earlier call (e.g. a failed hipMalloc the pool recovered from) is not ours */ \
     hipLaunchKernelGGL(kern, (grid), (block), (smem), (stream), __VA_ARGS__);                           \
     if (hipPeekAtLastError() != hipSuccess) ::star::rt_note_launch_error(#kern);                        \
   } while (0)

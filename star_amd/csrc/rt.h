@@ -24,7 +24,11 @@ inline void* event_record(hipStream_t) { return nullptr; }
 inline float event_elapsed_ms(void*, void*) { return 0.f; }
 inline void event_destroy(void*) {}
 #else
-inline int dev_malloc(void** p, size_t bytes) { return hipMalloc(p, bytes ? bytes : 256) == hipSuccess ? 0 : 1; }
+inline int dev_malloc(void** p, size_t bytes) {
+  if (hipMalloc(p, bytes ? bytes : 256) == hipSuccess) return 0;
+  (void)hipGetLastError();   // reported through the return value; do not leave it as HIP's sticky last error
+  return 1;
+}
 inline void dev_free(void* p) { (void)hipFree(p); }
 inline int memset_async(void* p, int v, size_t n, hipStream_t s) { return hipMemsetAsync(p, v, n, s) != hipSuccess; }
 inline int memcpy_h2d(void* d, const void* s, size_t n, hipStream_t st) { return hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, st) != hipSuccess; }

@@ -99,6 +99,7 @@ class Library:
         self.last_error = _sig(c, "star_last_error", ctypes.c_char_p, vp)
         self.set_stream = _sig(c, "star_set_stream", i32, vp, vp)
         self.sync = _sig(c, "star_sync", i32, vp)
+        self.pool_trim = _sig(c, "star_pool_trim", i32, vp)
         self.pool_bytes = _sig(c, "star_pool_bytes", sz, vp)
         self.pool_peak_bytes = _sig(c, "star_pool_peak_bytes", sz, vp)
         self.gemm = _sig(c, "star_gemm", i32, vp, ctypes.POINTER(GemmDesc))
@@ -156,6 +157,10 @@ class Context:
         self.h = h
         if not self.lib.is_hostemu:
             self.lib.set_stream(self.h, ctypes.c_void_p(torch.cuda.current_stream(self.device_index).cuda_stream))
+
+    def trim(self):
+        """give the arena's cached blocks back to the driver (phase boundaries; the reference calls torch.cuda.empty_cache() there)"""
+        self._check(self.lib.pool_trim(self.h), "pool_trim")
 
     def close(self):
         if getattr(self, "h", None):

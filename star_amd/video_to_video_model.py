@@ -147,6 +147,7 @@ class VideoToVideo_sr:
         bs = 1
 
         video_data_feature = self.vae_encode(video_data)
+        self.vae.ctx.trim()                      # reference: torch.cuda.empty_cache() (:94) -- the encoder's arena is not needed while sampling
         y = self._encode_text(y).to(dev)
 
         t = torch.LongTensor([total_noise_levels - 1]).to(dev)
@@ -163,6 +164,7 @@ class VideoToVideo_sr:
             chunk_executor=self.chunk_executor if chunk_inds is not None else None,
             **({"noise_sampler_cls": _cpu_noise_sampler(self.rng)} if self.rng is not None else {}))
 
+        self.generator.ctx.trim()                # reference: torch.cuda.empty_cache() (:124) -- the denoiser's arena is not needed while decoding
         vid_tensor_gen = self.vae_decode_chunk(gen_vid, chunk_size=3)
         w1, w2, h1, h2 = padding
         vid_tensor_gen = vid_tensor_gen[:, :, h1:h + h1, w1:w + w1]
