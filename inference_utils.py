@@ -1,6 +1,8 @@
 """Video I/O helpers with the reference's names (inference_utils.py:16-147).  cv2 / ffmpeg / torchvision are not in this
 image, so frames can also be exchanged as .npy / .pt tensors; OpenCV and ffmpeg are used when present."""
+import logging
 import os
+import shutil
 import subprocess
 import tempfile
 
@@ -19,53 +21,72 @@ def tensor2vid(video, mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5)):
 
 
 def preprocess(input_frames):
-    """list of HxWx3 uint8 RGB frames -> [F, 3, H, W] in [-1, 1] (inference_utils.py:26-35)."""
-    out = [torch.from_numpy(np.asarray(f)).permute(2, 0, 1).float() / 255.0 for f in input_frames]
-    return (torch.stack(out) - 0.5) / 0.5
+    """list of HxWx3 uint8 frames in OpenCV's BGR order, as `load_video` returns them -> [F, 3, H, W] RGB in [-1, 1].
+    Same contract as the reference (inference_utils.py:26-40: `frame[:, :, ::-1]`, to_tensor, clamp, (x - 0.5) / 0.5)."""
+    out = [torch.from_numpy(np.ascontiguousarray(np.asarray(f)[:, :, ::-1])).permute(2, 0, 1).float() / 255.0 for f in input_frames]
+    return (torch.stack(out).clamp_(0, 1) - 0.5) / 0.5
+
+
+def adjust_resolution(h, w, up_scale):
+    """target size rule of the reference (inference_utils.py:43-55): at least 720 rows, at most 1280x2048 pixels, even sides."""
+    if h * up_scale < 720:
+        s = 720 / h
+    elif h * w * up_scale * up_scale > 1280 * 2048:
+        s = float(np.sqrt(1280 * 2048 / (h * w)))
+    else:
+        s = up_scale
+    return int(s * h // 2 * 2), int(s * w // 2 * 2)
 
 
 def load_video(vid_path):
-    """-> (list of RGB uint8 frames, fps)."""
-    if vid_path.endswith(".npy"):
-        arr = np.load(vid_path)
-        return [f for f in arr], 8.0
-    if vid_path.endswith(".pt"):
-        arr = torch.load(vid_path)
-        return [f.numpy() for f in arr], 8.0
+    """-> (list of HxWx3 uint8 frames in BGR order, fps), like the reference's cv2 reader (inference_utils.py:67-86).
+    cv2 is not installed in this image: `.npy` / `.pt` files holding [F, H, W, 3] uint8 RGB frames are accepted as well
+    (and handed out in BGR, so that `preprocess` applies to every source alike)."""
+    if vid_path.endswith(".npy") or vid_path.endswith(".pt"):
+        arr = np.load(vid_path) if vid_path.endswith(".npy") else torch.load(vid_path).numpy()
+        return [np.ascontiguousarray(f[:, :, ::-1]) for f in arr], 8.0
     try:
         import cv2
     except ImportError as e:
-        raise RuntimeError("OpenCV is not installed here: pass frames as .npy / .pt ([F, H, W, 3] uint8)") from e
+        raise RuntimeError("OpenCV is not installed here: pass frames as .npy / .pt ([F, H, W, 3] uint8 RGB)") from e
     cap = cv2.VideoCapture(vid_path)
     fps = cap.get(cv2.CAP_PROP_FPS)
     frames = []
     while True:
         ok, frame = cap.read()
-        if not ok:
+        if not ok or frame is None:
             break
-        frames.append(cv2.cvtColor(frame, cv2.COLOR_BGR2RGB))
+        frames.append(frame)
     cap.release()
     return frames, fps
 
 
 def save_video(video, save_dir, file_name, fps=16.0):
-    """[F, H, W, 3] in 0..255 (float or uint8; truncated like the reference's astype('uint8')) -> mp4 through ffmpeg (libx264, crf 0) when available, else a .npy next to it."""
+    """[F, H, W, 3] RGB in 0..255 (float or uint8; truncated like the reference's astype('uint8')) -> mp4 through PNG frames
+    and `ffmpeg -crf 0` (inference_utils.py:89-106).  Returns the path actually written: without ffmpeg / PIL (this image)
+    the frames go to `<file_name minus extension>.npy` in the same directory, and the reason is logged."""
     os.makedirs(save_dir, exist_ok=True)
     out_path = os.path.join(save_dir, file_name)
     arr = video.cpu().numpy() if torch.is_tensor(video) else np.asarray(video)
     arr = arr.astype(np.uint8)
+    tmp = tempfile.mkdtemp()
     try:
         from PIL import Image
-        tmp = tempfile.mkdtemp()
         for i, f in enumerate(arr):
             Image.fromarray(f).save(os.path.join(tmp, "%06d.png" % (i + 1)))
-        cmd = f'ffmpeg -y -f image2 -framerate {fps} -i {tmp}/%06d.png -vcodec libx264 -crf 0 -pix_fmt yuv420p "{out_path}"'
-        if subprocess.call(cmd, shell=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) == 0:
+        cmd = ["ffmpeg", "-y", "-f", "image2", "-framerate", str(fps), "-i", os.path.join(tmp, "%06d.png"), "-vcodec", "libx264",
+               "-preset", "ultrafast", "-crf", "0", "-pix_fmt", "yuv420p", out_path]
+        r = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+        if r.returncode == 0:
             return out_path
-    except Exception:
-        pass
-    np.save(os.path.splitext(out_path)[0] + ".npy", arr)
-    return os.path.splitext(out_path)[0] + ".npy"
+        logging.getLogger("star_amd").error("save_video: ffmpeg failed (%d): %s", r.returncode, r.stderr.decode(errors="replace")[-400:])
+    except (ImportError, OSError) as e:     # no PIL / no ffmpeg binary
+        logging.getLogger("star_amd").warning("save_video: %s; writing frames as .npy instead of %s", e, out_path)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    npy = os.path.splitext(out_path)[0] + ".npy"
+    np.save(npy, arr)
+    return npy
 
 
 def collate_fn(data, device):

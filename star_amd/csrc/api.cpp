@@ -81,7 +81,16 @@ void star_ctx_destroy(star_ctx* h) {
 }
 
 const char* star_last_error(star_ctx* h) { return h ? h->c.err.c_str() : "null ctx"; }
-int star_set_stream(star_ctx* h, void* s) { h->c.stream = (hipStream_t)s; return 0; }
+int star_set_stream(star_ctx* h, void* s) {
+  // the arena hands freed blocks out again immediately on the assumption that all work is ordered on ONE stream: when the
+  // caller moves to another stream, everything enqueued on the old one is drained first (rare: once per torch stream context)
+  if (h->c.stream != (hipStream_t)s) {
+    rt::set_device(h->c.device);
+    if (rt::stream_sync(h->c.stream)) return h->c.fail(std::string("set_stream: sync of the previous stream failed: ") + rt::last_error_string());
+  }
+  h->c.stream = (hipStream_t)s;
+  return 0;
+}
 int star_sync(star_ctx* h) {
   if (h) rt::set_device(h->c.device);   // follow the context's device, not the caller's current one
   if (rt::stream_sync(h->c.stream)) return h->c.fail(std::string("sync failed: ") + rt::last_error_string());

@@ -74,7 +74,7 @@ STAR_DEV vec<T, 8> load_vt_frag(const char* vbuf, int kb0, int db, int lane) {
 // tile are dead by then, so their 32 registers are free) instead of two at a time just ahead of their use.
 // RING3 = 1 (variant 22): K/V tiles in a ring of three, the LDS-DMA of tile t+2 is issued at tile t and waited with a counted
 // vmcnt behind a raw s_barrier, so a tile never waits for a DMA issued only one tile earlier.
-template <class T, int NQ, int LAZY = 0, int ABL = 0, int ROWSUM = 0, int KPRE = 0, int RING3 = 0>   // NQ = 32-row query blocks per wave: 2 -> 2 waves/SIMD (256 VGPRs), 1 -> 4 waves/SIMD (128 VGPRs); ABL: ablation probes (bench only)
+template <class T, int NQ, int LAZY = 0, int ABL = 0, int ROWSUM = 0, int KPRE = 0, int RING3 = 0, int SPRIO = 0>   // NQ = 32-row query blocks per wave: 2 -> 2 waves/SIMD (256 VGPRs), 1 -> 4 waves/SIMD (128 VGPRs); ABL: ablation probes (bench only)
 STAR_GLOBAL void STAR_LAUNCH_BOUNDS(256, (NQ == 2 ? 2 : 4))
 flash_attn_v3_kernel(const AttnParams p) {
   constexpr int QW = 32 * NQ, QB = 4 * QW, KT = 64, TILE = KT * 128;
@@ -87,6 +87,10 @@ flash_attn_v3_kernel(const AttnParams p) {
   const int bh = xcd + 8 * (slot / p.nqb);
   const int qb = slot % p.nqb;
   if (bh >= p.batch * p.heads) return;
+  // static priority experiments (bench): one of the two workgroups that share a CU always wins the issue arbitration
+  if constexpr (SPRIO == 2) { if (bid & 1) STAR_SETPRIO(1); }
+  if constexpr (SPRIO == 3) { if ((bid >> 8) & 1) STAR_SETPRIO(1); }
+  if constexpr (SPRIO == 4) { if ((bid >> 3) & 1) STAR_SETPRIO(1); }
   const int b = bh / p.heads, hd = bh % p.heads;
   const T* __restrict__ Qg = (const T*)p.Q + (size_t)b * p.bsq + hd * 64;
   const T* __restrict__ Kg = (const T*)p.K + (size_t)b * p.bsk + hd * 64;
@@ -153,6 +157,7 @@ flash_attn_v3_kernel(const AttnParams p) {
     f32x16 s[NQ][2];
     // ---- S^T = K Q^T for query blocks [q_lo, q_hi) (8 + 1 MFMAs per block, independent accumulators)
     auto scores = [&](int q_lo, int q_hi) {
+      if constexpr (SPRIO == 1) STAR_SETPRIO(1);
 #pragma unroll
       for (int a = 0; a < NQ; ++a) {
         if (a < q_lo || a >= q_hi) continue;
@@ -195,6 +200,7 @@ flash_attn_v3_kernel(const AttnParams p) {
           }
         }
       }
+      if constexpr (SPRIO == 1) STAR_SETPRIO(0);
       if constexpr (MASK) {
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
@@ -311,6 +317,7 @@ flash_attn_v3_kernel(const AttnParams p) {
             }
         return;
       }
+      if constexpr (SPRIO == 1) STAR_SETPRIO(1);
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
@@ -323,6 +330,7 @@ flash_attn_v3_kernel(const AttnParams p) {
             oacc[qi][db] = mfma32<T>(vf, pf[qi][tt], oacc[qi][db]);
           }
         }
+      if constexpr (SPRIO == 1) STAR_SETPRIO(0);
     };
 
     if constexpr (LAZY == 0) {

@@ -37,7 +37,7 @@ def test_inference_script_end_to_end(tmp_path):
         assert frames.shape == (3, 96, 160, 3) and frames.dtype == np.uint8
         # the same run by hand: test() then the reference's two post-processing calls on the CPU oracle
         from inference_utils import preprocess
-        lr = preprocess([f for f in clip])
+        lr = preprocess([f[:, :, ::-1] for f in clip])      # preprocess takes BGR frames (the reference's cv2 contract)
         setup_seed(666)
         with torch.no_grad():
             out = star.model.test({"video_data": lr.cuda(), "y": prompt, "target_res": (96, 160)}, 900, steps=2,

@@ -1,0 +1,37 @@
+"""Contract of the frame helpers the CLI uses (reference inference_utils.py:16-106): BGR frames out of load_video, the flip
+inside preprocess, truncating uint8 conversion and clean-up in save_video."""
+import os
+
+import numpy as np
+import torch
+
+import inference_utils as iu
+
+
+def test_load_preprocess_roundtrip_is_rgb(tmp_path):
+    rgb = (np.random.RandomState(0).rand(2, 6, 8, 3) * 255).astype(np.uint8)
+    np.save(tmp_path / "clip.npy", rgb)
+    frames, fps = iu.load_video(str(tmp_path / "clip.npy"))
+    assert len(frames) == 2 and np.array_equal(frames[0], rgb[0][:, :, ::-1])          # BGR, as cv2 hands frames out
+    x = iu.preprocess(frames)
+    assert x.shape == (2, 3, 6, 8)
+    want = torch.from_numpy(rgb).permute(0, 3, 1, 2).float() / 255.0 * 2 - 1           # channel 0 is R again
+    assert torch.allclose(x, want, atol=1e-6)
+
+
+def test_adjust_resolution_rule():
+    assert iu.adjust_resolution(240, 426, 4) == (960, 1704)
+    assert iu.adjust_resolution(100, 160, 4) == (720, 1152)                             # at least 720 rows
+    assert iu.adjust_resolution(1080, 1920, 4) == (1214, 2158)                          # at most 1280 x 2048 pixels
+
+
+def test_save_video_returns_the_written_path_and_cleans_up(tmp_path, monkeypatch):
+    made = []
+    import tempfile
+    real = tempfile.mkdtemp
+    monkeypatch.setattr(tempfile, "mkdtemp", lambda *a, **k: made.append(real(*a, **k)) or made[-1])
+    vid = torch.rand(3, 8, 8, 3) * 255.9
+    path = iu.save_video(vid, str(tmp_path / "out"), "a.mp4", fps=8)
+    assert os.path.isfile(path) and made and not os.path.exists(made[0])
+    if path.endswith(".npy"):
+        assert np.array_equal(np.load(path), vid.numpy().astype(np.uint8))

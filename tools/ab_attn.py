@@ -15,7 +15,8 @@ def t_ms(fn, iters=3):
     return e0.elapsed_time(e1) / iters
 for (B, heads, N, tag) in [(8, 5, 26352, "L0"), (16, 10, 6696, "L1"), (32, 20, 1728, "L2")]:
     C = heads * 64
-    qkv = torch.randn(B, N, 3 * C, device=dev, dtype=dt)
+    fill = sys.argv[3] if len(sys.argv) > 3 else "randn"
+    qkv = torch.zeros(B, N, 3 * C, device=dev, dtype=dt) if fill == "zeros" else torch.randn(B, N, 3 * C, device=dev, dtype=dt) * (float(fill) if fill not in ("randn", "zeros") else 1.0)
     out = torch.empty(B, N, C, device=dev, dtype=dt)
     flops = 4.0 * B * heads * N * N * 64
     res = {v: [] for v in variants}
@@ -24,7 +25,7 @@ for (B, heads, N, tag) in [(8, 5, 26352, "L0"), (16, 10, 6696, "L1"), (32, 20, 1
     for rnd in range(3):
         for v in variants:
             res[v].append(t_ms(lambda: ctx.attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], heads, out=out, variant=v)))
-    print(tag, {v: "%.3f ms %.0f TF/s" % (min(r), flops / min(r) / 1e9) for v, r in res.items()}, flush=True)
+    print(tag, fill, {v: "%.3f ms %.0f TF/s" % (min(r), flops / min(r) / 1e9) for v, r in res.items()}, flush=True)
     if len(variants) > 1:
         o = {}
         for v in variants:
