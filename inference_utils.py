@@ -4,7 +4,8 @@ import logging
 import os
 import shutil
 import subprocess
-import tempfile
+import tempfile  # noqa: F401  (kept: callers of the reference module import it from here)
+import threading
 
 import numpy as np
 import torch
@@ -48,7 +49,9 @@ def load_video(vid_path):
     try:
         import cv2
     except ImportError as e:
-        raise RuntimeError("OpenCV is not installed here: pass frames as .npy / .pt ([F, H, W, 3] uint8 RGB)") from e
+        if _ffmpeg() is None:
+            raise RuntimeError("neither OpenCV nor ffmpeg is installed here: pass frames as .npy / .pt ([F, H, W, 3] uint8 RGB)") from e
+        return _load_video_ffmpeg(vid_path)
     cap = cv2.VideoCapture(vid_path)
     fps = cap.get(cv2.CAP_PROP_FPS)
     frames = []
@@ -61,29 +64,59 @@ def load_video(vid_path):
     return frames, fps
 
 
+def _ffmpeg():
+    return shutil.which("ffmpeg")
+
+
+def _load_video_ffmpeg(vid_path):
+    """decode through an ffmpeg pipe (bgr24 raw frames) when cv2 is missing."""
+    probe = subprocess.run([_ffmpeg().replace("ffmpeg", "ffprobe"), "-v", "error", "-select_streams", "v:0", "-show_entries",
+                            "stream=width,height,r_frame_rate", "-of", "csv=p=0", vid_path], capture_output=True, text=True)
+    w, h, rate = probe.stdout.strip().split(",")[:3]
+    num, den = (rate.split("/") + ["1"])[:2]
+    w, h = int(w), int(h)
+    raw = subprocess.run([_ffmpeg(), "-v", "error", "-i", vid_path, "-f", "rawvideo", "-pix_fmt", "bgr24", "-"], capture_output=True).stdout
+    frames = np.frombuffer(raw, dtype=np.uint8).reshape(-1, h, w, 3)
+    return [f for f in frames], float(num) / float(den or 1)
+
+
 def save_video(video, save_dir, file_name, fps=16.0):
-    """[F, H, W, 3] RGB in 0..255 (float or uint8; truncated like the reference's astype('uint8')) -> mp4 through PNG frames
-    and `ffmpeg -crf 0` (inference_utils.py:89-106).  Returns the path actually written: without ffmpeg / PIL (this image)
-    the frames go to `<file_name minus extension>.npy` in the same directory, and the reason is logged."""
+    """[F, H, W, 3] RGB in 0..255 (float or uint8; truncated like the reference's astype('uint8')) -> lossless H.264
+    (`-crf 0`, the reference's encoder settings, inference_utils.py:89-106).  The reference writes one PNG per frame into a
+    temp directory and lets ffmpeg read them back; here the raw RGB frames are streamed into ffmpeg's stdin from a writer
+    thread (no PNG encode + decode per frame, no temp files), which is what dominates once the model is fast (SURVEY.md
+    section 8f rank 2).  Returns the path actually written: without an ffmpeg binary (this image) the frames go to
+    `<file_name minus extension>.npy` in the same directory, and the reason is logged."""
     os.makedirs(save_dir, exist_ok=True)
     out_path = os.path.join(save_dir, file_name)
     arr = video.cpu().numpy() if torch.is_tensor(video) else np.asarray(video)
-    arr = arr.astype(np.uint8)
-    tmp = tempfile.mkdtemp()
-    try:
-        from PIL import Image
-        for i, f in enumerate(arr):
-            Image.fromarray(f).save(os.path.join(tmp, "%06d.png" % (i + 1)))
-        cmd = ["ffmpeg", "-y", "-f", "image2", "-framerate", str(fps), "-i", os.path.join(tmp, "%06d.png"), "-vcodec", "libx264",
-               "-preset", "ultrafast", "-crf", "0", "-pix_fmt", "yuv420p", out_path]
-        r = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
-        if r.returncode == 0:
+    arr = np.ascontiguousarray(arr.astype(np.uint8))
+    log = logging.getLogger("star_amd")
+    exe = _ffmpeg()
+    if exe is not None and arr.ndim == 4 and arr.shape[-1] == 3:
+        n, h, w, _ = arr.shape
+        cmd = [exe, "-y", "-f", "rawvideo", "-pix_fmt", "rgb24", "-s", f"{w}x{h}", "-framerate", str(fps), "-i", "-",
+               "-vcodec", "libx264", "-preset", "ultrafast", "-crf", "0", "-pix_fmt", "yuv420p", out_path]
+        proc = subprocess.Popen(cmd, stdin=subprocess.PIPE, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+
+        def feed():
+            try:
+                for f in arr:
+                    proc.stdin.write(f.tobytes())
+            except (BrokenPipeError, OSError):
+                pass
+            finally:
+                proc.stdin.close()
+
+        t = threading.Thread(target=feed, daemon=True)
+        t.start()
+        err = proc.stderr.read()
+        t.join()
+        if proc.wait() == 0:
             return out_path
-        logging.getLogger("star_amd").error("save_video: ffmpeg failed (%d): %s", r.returncode, r.stderr.decode(errors="replace")[-400:])
-    except (ImportError, OSError) as e:     # no PIL / no ffmpeg binary
-        logging.getLogger("star_amd").warning("save_video: %s; writing frames as .npy instead of %s", e, out_path)
-    finally:
-        shutil.rmtree(tmp, ignore_errors=True)
+        log.error("save_video: ffmpeg failed (%d): %s", proc.returncode, err.decode(errors="replace")[-400:])
+    else:
+        log.warning("save_video: no ffmpeg binary; writing frames as .npy instead of %s", out_path)
     npy = os.path.splitext(out_path)[0] + ".npy"
     np.save(npy, arr)
     return npy

@@ -25,13 +25,21 @@ def test_adjust_resolution_rule():
     assert iu.adjust_resolution(1080, 1920, 4) == (1214, 2158)                          # at most 1280 x 2048 pixels
 
 
-def test_save_video_returns_the_written_path_and_cleans_up(tmp_path, monkeypatch):
-    made = []
-    import tempfile
-    real = tempfile.mkdtemp
-    monkeypatch.setattr(tempfile, "mkdtemp", lambda *a, **k: made.append(real(*a, **k)) or made[-1])
+def test_save_video_returns_the_written_path(tmp_path):
     vid = torch.rand(3, 8, 8, 3) * 255.9
     path = iu.save_video(vid, str(tmp_path / "out"), "a.mp4", fps=8)
-    assert os.path.isfile(path) and made and not os.path.exists(made[0])
+    assert os.path.isfile(path) and os.listdir(tmp_path / "out") == [os.path.basename(path)]     # nothing else left behind
     if path.endswith(".npy"):
         assert np.array_equal(np.load(path), vid.numpy().astype(np.uint8))
+
+
+def test_save_video_streams_raw_frames_into_ffmpeg(tmp_path, monkeypatch):
+    """with an encoder on PATH the frames go down a pipe as rgb24 (no PNG round trip): a stand-in `ffmpeg` records its stdin."""
+    fake = tmp_path / "ffmpeg"
+    fake.write_text("#!/bin/sh\nfor a in \"$@\"; do out=\"$a\"; done\ncat > \"$out\"\n")
+    fake.chmod(0o755)
+    monkeypatch.setattr(iu, "_ffmpeg", lambda: str(fake))
+    vid = (torch.rand(4, 6, 10, 3) * 255).to(torch.uint8)
+    path = iu.save_video(vid, str(tmp_path / "out"), "b.mp4", fps=8)
+    assert path.endswith("b.mp4")
+    assert open(path, "rb").read() == vid.numpy().tobytes()
