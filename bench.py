@@ -173,6 +173,11 @@ def main():
                 "algorithmic_flops_per_launch": l0_flops, "avg_launch_ms": a["max_flops_ms"],
                 "all_self_attn_launches": {"launches": a["launches"], "ms": a["ms"], "TFLOP/s": a["flops"] / max(a["ms"], 1e-9) / 1e9}}
         roof["frac"] = roof["achieved"] / roof["peak"] if roof["achieved"] else None
+        # measured, not nominal: the same kernel with its softmax VALU removed (MFMA + LDS + barriers only) runs 1568 TF/s on N(0,1)
+        # operands and 2068 on zeros -- the chip is power-limited and full-entropy operands cost a quarter of the clock
+        # (profiles/r02_power_limit.txt).  `peak` stays the nominal dense MFMA figure the metric is defined against.
+        roof["mfma_skeleton_ceiling_on_random_operands"] = {"TFLOP/s": 1568.0, "source": "profiles/r02_power_limit.txt (variant 16, N(0,1) f16)",
+                                                            "frac_of_it": roof["achieved"] / 1568.0 if roof["achieved"] else None}
         breakdown = {k: {"ms": round(v["ms"], 1), "launches": v["launches"],
                          "TFLOP/s": round(v["flops"] / v["ms"] / 1e9, 1) if v["ms"] and v["flops"] else None,
                          "GB/s": round(v["bytes"] / v["ms"] / 1e6, 1) if v["ms"] else None} for k, v in prof_u.items()}

@@ -4,6 +4,7 @@ backend "emu": the SIMT-emulator build of the same kernel sources (index logic, 
 backend "hip": the real gfx950 library on a MI355X (-m gpu).  Both go through the C ABI.
 """
 import math
+import os
 
 import pytest
 import torch
@@ -39,11 +40,22 @@ def dev(ctx, t):
 PRODUCT_TILES = (0, 1, 2, 3, 4, 9)
 
 
+_BENCH_CTX = {}
+
+
 def need_variant(ctx, product_ok):
-    """A/B kernels and experimental tiles live only in -DSTAR_BENCH_VARIANTS builds (the emulator, tools/bench): on the
-    product library they must be REJECTED, which is asserted once in test_product_library_rejects_bench_variants."""
-    if not product_ok and not ctx.lib.has_bench_variants:
-        pytest.skip("bench-only variant: not in the product library")
+    """A/B kernels and experimental tiles live only in -DSTAR_BENCH_VARIANTS builds (the emulator, tools/bench): the product
+    library must REJECT them (test_product_library_rejects_bench_variants).  On hardware their parity tests run against the
+    bench build when it has been built (`make bench`), else they are skipped.  Returns the context to use."""
+    if product_ok or ctx.lib.has_bench_variants:
+        return ctx
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "bench", "libstar_hip_bench.so")
+    if not os.path.isfile(path):
+        pytest.skip("bench-only variant: not in the product library (build tools/bench with `make bench` to test it on hardware)")
+    key = ctx.dtype
+    if key not in _BENCH_CTX:
+        _BENCH_CTX[key] = L.Context(0, ctx.dtype, L.Library(path))
+    return _BENCH_CTX[key]
 
 
 def nhwc_rows(x):  # [N, C, H, W] -> [N*H*W, C]
@@ -60,7 +72,7 @@ GEMM_CASES = [  # M, N, K, tile
 
 @pytest.mark.parametrize("M,N,K,tile", GEMM_CASES)
 def test_gemm_bias_residual(ctx, dtype, M, N, K, tile):
-    need_variant(ctx, tile in PRODUCT_TILES)
+    ctx = need_variant(ctx, tile in PRODUCT_TILES)
     g = torch.Generator().manual_seed(M * 7 + N)
     A = torch.randn(M, K, generator=g).to(dtype)
     W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dtype)
@@ -158,7 +170,7 @@ G8_CASES = [  # M, N, K
 @pytest.mark.parametrize("tile", [20, 21])
 @pytest.mark.parametrize("M,N,K", G8_CASES)
 def test_gemm8_plain(ctx, dtype, M, N, K, tile):
-    need_variant(ctx, False)
+    ctx = need_variant(ctx, False)
     g = torch.Generator().manual_seed(M * 3 + N + K)
     A = torch.randn(M, K, generator=g).to(dtype)
     W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dtype)
@@ -174,7 +186,7 @@ def test_gemm8_plain(ctx, dtype, M, N, K, tile):
 @pytest.mark.parametrize("tile", [20, 21])
 def test_gemm8_matches_two_stage_kernel_bitwise(ctx, dtype, tile):
     """same MFMA shape, same k order, same fp32 accumulation: the two schedules must agree bit for bit."""
-    need_variant(ctx, False)
+    ctx = need_variant(ctx, False)
     g = torch.Generator().manual_seed(9)
     M, N, K = 1100, 512, 320
     A = torch.randn(M, K, generator=g).to(dtype)
@@ -188,7 +200,7 @@ def test_gemm8_matches_two_stage_kernel_bitwise(ctx, dtype, tile):
 @pytest.mark.parametrize("tile", [20, 21])
 @pytest.mark.parametrize("M,K,Nh", [(300, 128, 256), (1300, 320, 640)])
 def test_gemm8_geglu(ctx, dtype, M, K, Nh, tile):
-    need_variant(ctx, False)
+    ctx = need_variant(ctx, False)
     from star_amd.weights import geglu_interleave
     g = torch.Generator().manual_seed(5)
     A = torch.randn(M, K, generator=g).to(dtype)
@@ -204,7 +216,7 @@ def test_gemm8_geglu(ctx, dtype, M, K, Nh, tile):
 @pytest.mark.parametrize("tile", [20, 21])
 @pytest.mark.parametrize("NB,Cin,H,Wd,Cout", [(2, 64, 10, 8, 96), (5, 128, 18, 16, 264), (33, 64, 10, 8, 256)])
 def test_gemm8_conv3x3(ctx, dtype, NB, Cin, H, Wd, Cout, tile):
-    need_variant(ctx, False)
+    ctx = need_variant(ctx, False)
     g = torch.Generator().manual_seed(Cin + H)
     x = torch.randn(NB, Cin, H, Wd, generator=g).to(dtype)
     w = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)).to(dtype)
@@ -229,7 +241,7 @@ def test_gemm8_conv3x3(ctx, dtype, NB, Cin, H, Wd, Cout, tile):
 @pytest.mark.parametrize("tile", [20, 21])
 @pytest.mark.parametrize("Fr,H,Wd,C", [(5, 3, 4, 64), (9, 16, 16, 128), (1, 4, 4, 64)])
 def test_gemm8_temporal_conv(ctx, dtype, Fr, H, Wd, C, tile):
-    need_variant(ctx, False)
+    ctx = need_variant(ctx, False)
     g = torch.Generator().manual_seed(Fr)
     x = torch.randn(1, C, Fr, H, Wd, generator=g).to(dtype)
     w = (torch.randn(C, C, 3, 1, 1, generator=g) / math.sqrt(3 * C)).to(dtype)
@@ -253,7 +265,7 @@ def ref_attention(q, k, v, heads):
 @pytest.mark.parametrize("B,heads,Nq,Nk", [(2, 2, 300, 300), (1, 5, 80, 80), (3, 1, 257, 64), (1, 2, 64, 1), (9, 1, 33, 130), (1, 1, 130, 129)])
 def test_flash_attention_self(ctx, dtype, B, heads, Nq, Nk, variant):
     """spatial self-attention (unet_v2v.py:472 -> :184) on a fused QKV buffer, ragged q/k tails."""
-    need_variant(ctx, variant == 9)
+    ctx = need_variant(ctx, variant == 9)
     g = torch.Generator().manual_seed(Nq + Nk)
     C = heads * 64
     N = max(Nq, Nk)
@@ -295,7 +307,7 @@ def test_product_library_rejects_bench_variants(ctx, dtype):
 def test_flash_attention_variants_agree(ctx, dtype, variant):
     """all kernel variants (baseline / v2 / v3 with the augmented-k running max) against the fp32 reference, incl. a
     ragged key tail, strongly negative logits in tile 0 and a late spike that forces the rescale branch."""
-    need_variant(ctx, variant == 9)
+    ctx = need_variant(ctx, variant == 9)
     g = torch.Generator().manual_seed(21)
     B, heads, Nq, Nk = 2, 2, 200, 333
     q = torch.randn(B, Nq, 128, generator=g)
@@ -311,7 +323,7 @@ def test_flash_attention_variants_agree(ctx, dtype, variant):
 @pytest.mark.parametrize("variant", [2, 6, 7, 8, 9, 10, 15, 20, 21, 22])
 def test_flash_attention_forced_rescale(ctx, dtype, variant):
     """a key spike late in the sequence forces the online-softmax rescale branch with a large max jump."""
-    need_variant(ctx, variant == 9)
+    ctx = need_variant(ctx, variant == 9)
     g = torch.Generator().manual_seed(11)
     B, heads, N = 1, 1, 400
     q = torch.randn(B, N, 64, generator=g)
@@ -329,7 +341,7 @@ def test_flash_attention_growing_max(ctx, dtype, variant):
     """scores that keep growing along the key axis (every tile moves the maximum by several binades, some by more than
     the fp16 exponent range) and a first tile far below everything that follows: the lazy-max variants must take their
     recompute path tile after tile and still match."""
-    need_variant(ctx, variant == 9)
+    ctx = need_variant(ctx, variant == 9)
     g = torch.Generator().manual_seed(31)
     B, heads, N = 1, 2, 520
     q = torch.randn(B, N, 128, generator=g)
