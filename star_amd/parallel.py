@@ -25,7 +25,7 @@ _DTYPES = [torch.float32, torch.float16, torch.bfloat16, torch.float64]
 def _gather_ints(vec, group, device):
     """all-gather of a small int64 vector (metadata only; runs once per plan, see _RaggedPlan)."""
     world, _ = _world(group)
-    v = vec.to(device)
+    v = vec.to(device if dist.get_backend(group) == "nccl" else "cpu")
     outs = [torch.empty_like(v) for _ in range(world)]
     dist.all_gather(outs, v, group=group)
     return torch.stack(outs).cpu()
@@ -77,8 +77,14 @@ def _all_gather_ragged(parts, dim, group, cache=None, key=None):
     if parts:
         cat = torch.cat(parts, dim=dim)
         buf.narrow(dim, 0, cat.shape[dim]).copy_(cat)
-    outs = [torch.empty_like(buf) for _ in range(world)]
-    dist.all_gather(outs, buf, group=group)      # RCCL all-gather over xGMI (C1 / C2)
+    if dist.get_backend(group) == "gloo" and buf.is_cuda:   # plumbing tests on a 1-GPU box: stage through the host
+        host = buf.cpu()
+        houts = [torch.empty_like(host) for _ in range(world)]
+        dist.all_gather(houts, host, group=group)
+        outs = [o.to(device) for o in houts]
+    else:
+        outs = [torch.empty_like(buf) for _ in range(world)]
+        dist.all_gather(outs, buf, group=group)      # RCCL all-gather over xGMI (C1 / C2)
     result = []
     for r in range(world):
         off, lst = 0, []

@@ -102,7 +102,7 @@ def test_gemm_strided_views(ctx, dtype):
 @pytest.mark.parametrize("M,K,Nh", [(70, 64, 128), (300, 320, 1280)])
 def test_gemm_geglu(ctx, dtype, M, K, Nh):
     """GEGLU epilogue (unet_v2v.py:496-504) with value/gate weight rows interleaved in 32-row blocks."""
-    from star_amd.weights import geglu_interleave
+    from star_amd.topology import geglu_interleave
     g = torch.Generator().manual_seed(5)
     A = torch.randn(M, K, generator=g).to(dtype)
     Wg = (torch.randn(2 * Nh, K, generator=g) / math.sqrt(K)).to(dtype)
@@ -201,7 +201,7 @@ def test_gemm8_matches_two_stage_kernel_bitwise(ctx, dtype, tile):
 @pytest.mark.parametrize("M,K,Nh", [(300, 128, 256), (1300, 320, 640)])
 def test_gemm8_geglu(ctx, dtype, M, K, Nh, tile):
     ctx = need_variant(ctx, False)
-    from star_amd.weights import geglu_interleave
+    from star_amd.topology import geglu_interleave
     g = torch.Generator().manual_seed(5)
     A = torch.randn(M, K, generator=g).to(dtype)
     Wg = (torch.randn(2 * Nh, K, generator=g) / math.sqrt(K)).to(dtype)

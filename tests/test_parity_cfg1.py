@@ -83,6 +83,24 @@ def test_denoiser_on_identical_latents_matches_the_reference(pipeline):
 
 
 @pytest.mark.gpu
+def test_vae_encode_16_bit_storage_vs_the_fp32_encode_of_the_reference_path(pipeline):
+    """the reference encodes in fp32 (vae.encode runs outside autocast, video_to_video_model.py:93); the HIP encoder keeps fp32
+    accumulation but 16-bit activations.  Measured here on the eight 720x1280 frames of cfg1 against the fp32 CPU encode with
+    the same posterior noise: the latent must agree far inside the 50 dB bar, otherwise an fp32-storage encoder would be needed."""
+    model, video, y, neg, gold, CFG1 = pipeline
+    from star_amd.geometry import pad_to_fit
+    dev = model._tensor_device
+    th, tw = CFG1["target"]
+    padded = model.generator.ctx.resize_pad(video.to(dev, torch.float32), (th, tw), pad_to_fit(th, tw), 1.0).unsqueeze(0)
+    model.rng.manual_seed(CFG1["rng_seed"])
+    z = model.vae_encode(padded).cpu()
+    rng = float(gold["z"].max() - gold["z"].min())
+    p = psnr(z, gold["z"], rng)
+    print(f"cfg1 VAE encode, 16-bit activations vs fp32 CPU encode: latent PSNR {p:.1f} dB (range {rng:.2f})")
+    assert p >= 60.0, p
+
+
+@pytest.mark.gpu
 def test_whole_test_call_psnr_at_least_50_db(pipeline):
     """`VideoToVideo_sr.test()` end to end (resize + pad, VAE encode, sampling, VAE decode, crop) against the decoded reference
     output: the stated bar, asserted."""
