@@ -97,6 +97,18 @@ def main():
                 s = timeit(lambda: ctx.gemm(A, Wt, bias=b, out=out, geglu=geglu, force_tile=tile))
                 rec(f"gemm {tag} M={M} N={N} K={K} tile={tile}", s, flops=2.0 * M * N * K, bytes_=(A.numel() + out.numel()) * 2)
             del A, Wt, out
+        # the residual-add epilogue (attention out-projection, FF out, proj_out: + x)
+        for (M, N, K, tag) in [(tok, 320, 320, "L0 proj+res"), (tok, 320, 1280, "L0 ff-out+res"), (tok // 4, 640, 640, "L1 proj+res"),
+                               (tok // 4, 640, 2560, "L1 ff-out+res"), (tok // 16 + 1536, 1280, 1280, "L2 proj+res")]:
+            A = torch.randn(M, K, device=dev, dtype=dt)
+            Wt = torch.randn(N, K, device=dev, dtype=dt) * 0.05
+            b = torch.randn(N, device=dev)
+            R = torch.randn(M, N, device=dev, dtype=dt)
+            out = torch.empty(M, N, device=dev, dtype=dt)
+            for tile in ([0] if not args.tiles else [int(t) for t in args.tiles.split(",")]):
+                s = timeit(lambda: ctx.gemm(A, Wt, bias=b, res=R, out=out, force_tile=tile))
+                rec(f"gemm {tag} M={M} N={N} K={K} tile={tile}", s, flops=2.0 * M * N * K, bytes_=(A.numel() + 2 * out.numel()) * 2)
+            del A, Wt, out, R
     if want("conv"):
         for (NB, Cin, Hh, Ww, Cout, tag) in [(32, 320, 122, 216, 320, "L0 320->320"), (32, 640, 62, 108, 640, "L1 640->640"),
                                              (32, 1280, 32, 54, 1280, "L2 1280->1280"), (32, 2560, 17, 27, 1280, "L3 2560->1280")]:
