@@ -128,6 +128,12 @@ int star_unet_forward(star_ctx* ctx, const float* xt, int64_t t, const float* y,
  * self-attention of each net's first spatial transformer) is computed once. */
 int star_unet_forward_cfg(star_ctx* ctx, const float* xt, int64_t t, const float* y_cond, const float* y_uncond,
                           const float* hint, float* out_cond, float* out_uncond, int32_t f, int32_t h, int32_t w);
+/* replaces: VideoControlNet.forward (unet_v2v.py:2134-2206) on its own -- the 13 residuals ControlledV2VUNet.forward adds to the skip
+ * connections and the middle block (:1746-1748, 1790-1800): residuals[i] receives channels-last rows [f * H_i * W_i, C_i] in the
+ * context's storage dtype, i = 0..11 the zero-conv'd encoder outputs (level sizes (H, W) -> (H/2 + 1, W/2) per Downsample), 12 the
+ * middle block's.  star_unet_forward computes the same tensors internally; this entry exists so that parity tests can look at them. */
+int star_controlnet_forward(star_ctx* ctx, const float* xt, int64_t t, const float* y, const float* hint, void* const* residuals,
+                            int32_t n_residuals, int32_t f, int32_t h, int32_t w);
 /* one reference module (ResBlock / SpatialTransformer / TemporalTransformer / Downsample / Upsample) built from
  * staged tensors `prefix.*`; kind: 0 res, 1 spatial, 2 temporal, 3 down, 4 up.  x/out: channels-last rows (ctx dtype) */
 int star_module_run(star_ctx* ctx, int32_t kind, const char* prefix, int32_t cin, int32_t cout, int32_t heads,

@@ -73,6 +73,24 @@ def gen_unet(cfg, cases, tag, wseed=0):
         print("wrote", path, tuple(out.shape), float(out.abs().mean()))
 
 
+CONTROL_CASE = (3, 18, 16, 106)
+
+
+def gen_control(cfg, wseed=0):
+    """the 13 residuals of the REFERENCE's VideoControlNet.forward (unet_v2v.py:2134-2206) on a reduced-width net: what
+    ControlledV2VUNet.forward adds to the skip connections and the middle block (row a2 of SURVEY.md section 8)."""
+    net = build_reference_unet(cfg)
+    net.load_state_dict(random_state_dict(cfg, seed=wseed), strict=True)
+    f, h, w, seed = CONTROL_CASE
+    x, t, y, hint = unet_inputs(cfg, f, h, w, seed)
+    with torch.no_grad():
+        res = net.VideoControlNet(x, t, y, hint=hint)
+    assert len(res) == 13
+    path = os.path.join(GOLD, f"unet_small_control_f{f}_{h}x{w}.pt")
+    torch.save({"residuals": [r.clone() for r in res], "case": CONTROL_CASE, "wseed": wseed}, path)
+    print("wrote", path, [tuple(r.shape) for r in res])
+
+
 def gen_shapes():
     m = ref_loader.load_unet_module()
     with torch.device("meta"):
@@ -242,5 +260,7 @@ if __name__ == "__main__":
         gen_frames()
     if only is None or "small" in only:
         gen_unet(SMALL_TEST_CONFIG, SMALL_CASES, "small")
+    if only is None or "control" in only:
+        gen_control(SMALL_TEST_CONFIG)
     if a.full:
         gen_unet(UNetConfig(), [(2, 10, 8, 201)], "full")

@@ -208,6 +208,11 @@ int star_unet_forward_cfg(star_ctx* h, const float* xt, int64_t t, const float* 
   float* outs[2] = {out_cond, out_uncond};
   return finish(h, unet_forward_n(&h->c, xt, (long long)t, ys, hint, outs, 2, f, hh, w));
 }
+int star_controlnet_forward(star_ctx* h, const float* xt, int64_t t, const float* y, const float* hint, void* const* residuals,
+                            int32_t n_residuals, int32_t f, int32_t hh, int32_t w) {
+  if (h) rt::set_device(h->c.device);
+  return finish(h, controlnet_forward(&h->c, xt, (long long)t, y, hint, residuals, n_residuals, f, hh, w));
+}
 int star_module_run(star_ctx* h, int32_t kind, const char* prefix, int32_t cin, int32_t cout, int32_t heads, int32_t embed_dim,
                     int32_t context_dim, const void* x, const float* emb, const float* context, void* out, int32_t f, int32_t hh, int32_t w) {
   if (h) rt::set_device(h->c.device);   // follow the context's device, not the caller's current one

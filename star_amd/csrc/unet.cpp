@@ -389,7 +389,7 @@ static int time_embedding(Ctx* ctx, const Net& net, long long t, int dim, int E,
 }
 
 int unet_forward_n(Ctx* ctx, const float* xt, long long t, const float* const* ys, const float* hint, float* const* outs, int nb,
-                   int F, int H, int W) {
+                   int F, int H, int W, void* const* control_tap, int n_tap) {
   if (!ctx->unet) return ctx->fail("unet_forward: no model built (star_unet_build)");
   if (nb < 1 || nb > 2) return ctx->fail("unet_forward: 1 or 2 guidance branches");
   const UNetModel& M = *ctx->unet;
@@ -457,6 +457,14 @@ int unet_forward_n(Ctx* ctx, const float* xt, long long t, const float* const* y
     if (f.rc) return f.rc;
     control.push_back(lin(x, net.middle_out));
   }
+  if (control_tap) {   // star_controlnet_forward: hand the residuals out (channels-last rows, storage dtype) and stop
+    if (n_tap != (int)control.size()) return ctx->fail("controlnet_forward: expected " + std::to_string(control.size()) + " residual buffers");
+    for (int i = 0; i < n_tap; ++i) {
+      const Act& a = control[i].a[0];
+      rt::memcpy_d2d(control_tap[i], a.p(), (size_t)f.rows(a) * a.C * f.es, ctx->stream);
+    }
+    return f.rc;
+  }
   // ---------------- main UNet (unet_v2v.py:1765-1808)
   const Net& net = M.main;
   f.emb = emb_main.as<float>();
@@ -519,6 +527,13 @@ int unet_forward(Ctx* ctx, const float* xt, long long t, const float* y, const f
   const float* ys[1] = {y};
   float* outs[1] = {out};
   return unet_forward_n(ctx, xt, t, ys, hint, outs, 1, F, H, W);
+}
+
+int controlnet_forward(Ctx* ctx, const float* xt, long long t, const float* y, const float* hint, void* const* residuals, int n,
+                       int F, int H, int W) {
+  const float* ys[1] = {y};
+  float* outs[1] = {nullptr};
+  return unet_forward_n(ctx, xt, t, ys, hint, outs, 1, F, H, W, residuals, n);
 }
 
 int module_run(Ctx* ctx, int kind, const char* prefix, int cin, int cout, int heads, int embed_dim, int context_dim,

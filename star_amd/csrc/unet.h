@@ -66,7 +66,11 @@ int unet_build(Ctx* ctx, const UNetCfg& cfg);
 int unet_forward(Ctx* ctx, const float* xt, long long t, const float* y, const float* hint, float* out, int F, int H, int W);
 // nb = 1 or 2 guidance branches (different text contexts) sharing all context-independent work
 int unet_forward_n(Ctx* ctx, const float* xt, long long t, const float* const* ys, const float* hint, float* const* outs, int nb,
-                   int F, int H, int W);
+                   int F, int H, int W, void* const* control_tap = nullptr, int n_tap = 0);
+// VideoControlNet.forward alone (unet_v2v.py:2134-2206): the zero-conv'd residuals of the encoder half + the middle block,
+// as channels-last rows [F*H_l*W_l, C_l] in the storage dtype
+int controlnet_forward(Ctx* ctx, const float* xt, long long t, const float* y, const float* hint, void* const* residuals, int n,
+                       int F, int H, int W);
 // run one module built on the fly from staged tensors `prefix.*` (unit parity against reference blocks)
 int module_run(Ctx* ctx, int kind, const char* prefix, int cin, int cout, int heads, int embed_dim, int context_dim,
                const void* x, const float* emb, const float* context, void* out, int F, int H, int W);

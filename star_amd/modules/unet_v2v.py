@@ -29,6 +29,7 @@ def _bind(lib):
     lib.load_tensor = L._sig(c, "star_load_tensor", i32, vp, ctypes.c_char_p, vp, ctypes.POINTER(i64), i32, i32)
     lib.unet_build = L._sig(c, "star_unet_build", i32, vp, ctypes.POINTER(UNetConfigC))
     lib.unet_forward = L._sig(c, "star_unet_forward", i32, vp, vp, i64, vp, vp, vp, i32, i32, i32)
+    lib.controlnet_forward = L._sig(c, "star_controlnet_forward", i32, vp, vp, i64, vp, vp, ctypes.POINTER(vp), i32, i32, i32, i32)
     lib.unet_forward_cfg = L._sig(c, "star_unet_forward_cfg", i32, vp, vp, i64, vp, vp, vp, vp, vp, i32, i32, i32)
     lib.module_run = L._sig(c, "star_module_run", i32, vp, i32, ctypes.c_char_p, i32, i32, i32, i32, i32, vp, vp, vp, vp, i32, i32, i32)
     lib.clear_staged = L._sig(c, "star_clear_staged", i32, vp)
@@ -161,6 +162,36 @@ class ControlledV2VUNet:
         ctx._check(ctx.lib.unet_forward(ctx.h, L._ptr(xf), tt, L._ptr(yf), L._ptr(hf), L._ptr(out), f, h, w), "unet_forward")
         self.batch = b
         return out if x.dtype == torch.float32 else out.to(x.dtype)
+
+
+def _control_residuals(self, x, t, y, hint):
+    """`VideoControlNet.forward` alone (unet_v2v.py:2134-2206) -> list of 13 float32 tensors [(f), C_l, H_l, W_l] (the reference's
+    return value): 12 zero-conv'd encoder outputs + the middle block's."""
+    cfg, ctx = self.cfg, self.ctx
+    ctx.use_current_stream()
+    dev = ctx.torch_device
+    b, c, f, h, w = x.shape
+    shapes = []
+    ch, hh, ww = cfg.dim, h, w
+    shapes.append((ch, hh, ww))                                   # input_blocks.0 (stem)
+    for li, mult in enumerate(cfg.dim_mult):
+        ch = cfg.dim * mult
+        shapes += [(ch, hh, ww)] * cfg.num_res_blocks
+        if li != len(cfg.dim_mult) - 1:
+            hh, ww = hh // 2 + 1, ww // 2
+            shapes.append((ch, hh, ww))                           # Downsample
+    shapes.append((ch, hh, ww))                                   # middle_block_out
+    bufs = [torch.empty(f * sh * sw, sc, dtype=ctx.dtype, device=dev) for (sc, sh, sw) in shapes]
+    ptrs = (ctypes.c_void_p * len(bufs))(*[bb.data_ptr() for bb in bufs])
+    xf = x.to(device=dev, dtype=torch.float32).contiguous()
+    hf = hint.to(device=dev, dtype=torch.float32).contiguous()
+    yf = y.to(device=dev, dtype=torch.float32).reshape(77, cfg.context_dim).contiguous()
+    tt = int(t.reshape(-1)[0]) if torch.is_tensor(t) else int(t)
+    ctx._check(ctx.lib.controlnet_forward(ctx.h, L._ptr(xf), tt, L._ptr(yf), L._ptr(hf), ptrs, len(bufs), f, h, w), "controlnet_forward")
+    return [bb.float().reshape(f, sh, sw, sc).permute(0, 3, 1, 2).contiguous() for bb, (sc, sh, sw) in zip(bufs, shapes)]
+
+
+ControlledV2VUNet.control_residuals = _control_residuals
 
 
 def _cfg_pair(self, x, t, y_cond, y_uncond, hint=None, hint_chunk=None, **unused):

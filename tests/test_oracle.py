@@ -22,7 +22,7 @@ def small_sd():
     return random_state_dict(SMALL_TEST_CONFIG, seed=0)
 
 
-@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "unet_small_*.pt"))), ids=os.path.basename)
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "unet_small_f*.pt"))), ids=os.path.basename)
 def test_oracle_unet_matches_reference_golden(path, small_sd):
     gold = torch.load(path)
     f, h, w, seed = gold["case"]
@@ -32,6 +32,19 @@ def test_oracle_unet_matches_reference_golden(path, small_sd):
     out = O.unet_forward(small_sd, SMALL_TEST_CONFIG, x, t, y, hint)
     err = float((out - gold["out"]).abs().max())
     assert err < 2e-4 * max(1.0, float(gold["out"].abs().max())), err
+
+
+def test_oracle_control_residuals_match_reference_golden(small_sd):
+    """the 13 residuals of the reference's VideoControlNet.forward (row a2)."""
+    gold = torch.load(os.path.join(GOLD, "unet_small_control_f3_18x16.pt"))
+    f, h, w, seed = gold["case"]
+    x, t, y, hint = unet_inputs(SMALL_TEST_CONFIG, f, h, w, seed)
+    from star_amd.topology import build_blocks
+    res = O.control_net_forward(small_sd, SMALL_TEST_CONFIG, build_blocks(SMALL_TEST_CONFIG, control=True), x, t, y, hint)
+    assert len(res) == len(gold["residuals"]) == 13
+    for i, (a, b) in enumerate(zip(res, gold["residuals"])):
+        assert a.shape == b.shape, i
+        assert float((a - b).abs().max()) < 2e-4 * max(1.0, float(b.abs().max())), i
 
 
 def test_oracle_blocks_match_reference_golden():

@@ -68,7 +68,7 @@ def _small_model(backend, dtype, request):
     return net
 
 
-SMALL_GOLD = sorted(glob.glob(os.path.join(GOLD, "unet_small_*.pt")))
+SMALL_GOLD = sorted(glob.glob(os.path.join(GOLD, "unet_small_f*.pt")))
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
@@ -85,6 +85,40 @@ def test_small_unet_matches_reference_golden(backend, dtype, request):
         out = net(x.to(dev), t=t, y=y.to(dev), hint=hint.to(dev))
         e = rel_rms(out, gold["out"])
         assert e < REL_RMS[dtype][1], (os.path.basename(path), e, psnr(out, gold["out"]))
+
+
+def test_control_residuals_match_reference_golden(backend, request):
+    """`star_controlnet_forward`: the 13 tensors VideoControlNet.forward returns (unet_v2v.py:2134-2206), each against the
+    reference's own (the zero-convs are re-drawn non-zero in the fixtures, so none of them is vacuous)."""
+    net = _small_model(backend, torch.float16, request)
+    gold = torch.load(os.path.join(GOLD, "unet_small_control_f3_18x16.pt"))
+    f, h, w, seed = gold["case"]
+    x, t, y, hint = unet_inputs(SMALL_TEST_CONFIG, f, h, w, seed)
+    dev = net.ctx.torch_device
+    res = net.control_residuals(x.to(dev), t, y.to(dev), hint.to(dev))
+    assert len(res) == 13
+    for i, (a, b) in enumerate(zip(res, gold["residuals"])):
+        assert tuple(a.shape) == tuple(b.shape), (i, a.shape, b.shape)
+        assert float(b.abs().max()) > 1e-3, i
+        e = rel_rms(a, b)
+        assert e < REL_RMS[torch.float16][1], (i, e)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+def test_long_chunk_more_than_64_frames(dtype):
+    """chunks of 65-128 frames (the reference's make_chunks yields an 80-frame tail with --max_chunk_len 64): the temporal
+    attention runs with three / four 32-frame blocks per wave."""
+    import unet_oracle as O
+    net = ControlledV2VUNet(SMALL_TEST_CONFIG, dtype=dtype)
+    sd = random_state_dict(SMALL_TEST_CONFIG, seed=0)
+    net.load_state_dict(sd)
+    for f in (70, 100):
+        x, t, y, hint = unet_inputs(SMALL_TEST_CONFIG, f, 10, 8, 300 + f)
+        out = net(x.cuda(), t=t, y=y.cuda(), hint=hint.cuda())
+        ref = O.unet_forward(sd, SMALL_TEST_CONFIG, x, t, y, hint)
+        e = rel_rms(out, ref)
+        assert e < REL_RMS[dtype][1], (f, e)
 
 
 @pytest.mark.gpu
