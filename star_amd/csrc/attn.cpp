@@ -56,6 +56,7 @@ static int launch_flash(Ctx* ctx, const AttnArgs& a) {
   else if (a.variant == 24) STAR_LAUNCH((flash_attn_v3_kernel<T, 2, 1, 0, 1, 0, 0, 2>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);   // static priority for odd workgroups
   else if (a.variant == 25) STAR_LAUNCH((flash_attn_v3_kernel<T, 2, 1, 0, 1, 0, 0, 3>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);   // ... by bit 8 of the block id
   else if (a.variant == 26) STAR_LAUNCH((flash_attn_v3_kernel<T, 2, 1, 0, 1, 0, 0, 4>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);   // ... by bit 3
+  else if (a.variant == 27) STAR_LAUNCH((flash_attn_v3_kernel<T, 2, 1, 0, 1, 0, 2>), dim3((unsigned)nblk), dim3(256), (size_t)65536, ctx->stream, p);   // key tiles in pairs: one barrier per 128 keys
   else if (a.variant == 21) STAR_LAUNCH((flash_attn_v3_kernel<T, 2, 1, 0, 1, 1>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);
   else if (a.variant == 22) STAR_LAUNCH((flash_attn_v3_kernel<T, 2, 1, 0, 1, 0, 1>), dim3((unsigned)nblk), dim3(256), (size_t)(3 * 16384), ctx->stream, p);
   else if (a.variant == 20) {   // enforced antiphase, 512-row workgroups

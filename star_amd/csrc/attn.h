@@ -152,7 +152,7 @@ flash_attn_v3_kernel(const AttnParams p) {
     constexpr bool MASK = decltype(mask_tag)::value;
     constexpr bool FIRST = decltype(first_tag)::value;   // LAZY == 3: the first key tile is peeled out of the loop
     constexpr float LAZY_BIG = 1024.0f;
-    const char* kbuf = smem + (RING3 ? t % 3 : (t & 1)) * 2 * TILE;
+    const char* kbuf = smem + (RING3 == 2 ? (((t >> 1) & 1) * 2 + (t & 1)) : RING3 ? t % 3 : (t & 1)) * 2 * TILE;
     const char* vbuf = kbuf + TILE;
     f32x16 s[NQ][2];
     // ---- S^T = K Q^T for query blocks [q_lo, q_hi) (8 + 1 MFMAs per block, independent accumulators)
@@ -635,6 +635,23 @@ flash_attn_v3_kernel(const AttnParams p) {
       glds_wait(); block_sync();
       if (nt == 1) tile(0, std::true_type{}, std::true_type{});
       else tile(nt - 1, std::true_type{}, std::false_type{});
+    }
+  } else if constexpr (RING3 == 2) {
+    // (bench) key tiles in PAIRS: one barrier + one DMA wait per 128 keys; the next pair lands while this pair is computed.
+    // Four 16 KB slots (64 KB per workgroup, two workgroups per CU still fit)
+    auto slot = [](int t) { return ((t >> 1) & 1) * 2 + (t & 1); };
+    if (nt > 1) stage(1, slot(1));
+    for (int t = 0; t < nfull; ++t) {
+      if ((t & 1) == 0) {
+        glds_wait(); block_sync();
+        if (t + 2 < nt) stage(t + 2, slot(t + 2));
+        if (t + 3 < nt) stage(t + 3, slot(t + 3));
+      }
+      tile(t, std::false_type{}, std::false_type{});
+    }
+    if (has_tail) {
+      if (((nt - 1) & 1) == 0) { glds_wait(); block_sync(); }
+      tile(nt - 1, std::true_type{}, std::false_type{});
     }
   } else if constexpr (RING3 == 1) {
     if (nt > 1) stage(1, 1);

@@ -111,6 +111,7 @@ static int launch_gemm(Ctx* ctx, const GemmArgs& a) {
     case 36: return launch_gemm8_r<T, false, 6>(ctx, a, 256);
     case 37: return launch_gemm8_r<T, false, 7>(ctx, a, 256);
     case 38: return launch_gemm8_r<T, false, 8>(ctx, a, 256);
+    case 39: return (a.epi & EPI_RES) ? launch_gemm8_r<T, true, 9>(ctx, a, 256) : launch_gemm8_r<T, false, 9>(ctx, a, 256);   // gemm8 without the stagger (correct results)
 #endif
   }
 #ifdef STAR_BENCH_VARIANTS

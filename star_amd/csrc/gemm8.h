@@ -55,7 +55,7 @@ STAR_DEV void glds4(const void* gsrc, void* lds_wave_base) {
 #endif
 }
 
-template <class T, int AMODE, bool RES, int ABL = 0>   // ABL: timing ablations (bench build only; results are garbage): 1 no DMA in the loop, 2 no fragment reads, 3 neither, 4 neither + no barriers, 5 neither + one barrier per phase, 6 DMA from a hot 64 KB region (always cache hits), 7 no A DMA, 8 no B DMA
+template <class T, int AMODE, bool RES, int ABL = 0>   // ABL: timing ablations (bench build only; results are garbage): 1 no DMA in the loop, 2 no fragment reads, 3 neither, 4 neither + no barriers, 5 neither + one barrier per phase, 6 DMA from a hot 64 KB region (always cache hits), 7 no A DMA, 8 no B DMA; 9 = a REAL variant (correct results): no stagger between the two wave groups (all eight waves in phase)
 // RES: residual add in the epilogue (compile time: a run-time branch around the loads would make hipcc's vmcnt waits inexact)
 STAR_GLOBAL void STAR_LAUNCH_BOUNDS(512, 2)
 gemm8_kernel(const GemmParams p) {
@@ -240,7 +240,7 @@ gemm8_kernel(const GemmParams p) {
   a_issue(n1, 1, 0, G8::OFF_A0); b_issue(n1, 1, 1, G8::OFF_B1);
   if (n1.valid) { STAR_WAIT_VMCNT(4); } else { STAR_WAIT_VMCNT(0); }
   raw_barrier();
-  if (wr == 1) raw_barrier();   // wave row 1 runs half a phase behind wave row 0
+  if (ABL != 9 && wr == 1) raw_barrier();   // wave row 1 runs half a phase behind wave row 0
 
   zero_acc();
   const int S = my_tiles * nk;
@@ -374,7 +374,7 @@ gemm8_kernel(const GemmParams p) {
     cur = n1; n1 = n2; advance(n2);
     abl_first = false;
   }
-  if (wr == 0) raw_barrier();
+  if (ABL != 9 && wr == 0) raw_barrier();
 }
 
 }  // namespace star

@@ -9,10 +9,13 @@ tiles = [int(t) for t in (sys.argv[1] if len(sys.argv) > 1 else "1,20,31,32,33,3
 fill = sys.argv[2] if len(sys.argv) > 2 else "randn"   # randn | zeros | small (integers -2..2)
 NAMES = {1: "2-stage 256x256 (round 1)", 2: "2-stage 256x320", 20: "gemm8", 31: "gemm8 no DMA in loop", 32: "gemm8 no fragment reads",
          33: "gemm8 no DMA, no reads", 34: "gemm8 MFMA only (no barriers)", 35: "gemm8 no DMA/reads, 1 barrier per phase",
-         36: "gemm8 DMA from a hot 64 KB region", 37: "gemm8 no A DMA", 38: "gemm8 no B DMA"}
+         36: "gemm8 DMA from a hot 64 KB region", 37: "gemm8 no A DMA", 38: "gemm8 no B DMA", 39: "gemm8 without stagger (correct)"}
 dt = torch.float16
 ctx = L.Context(0, dt, L.Library(os.path.join(ROOT, "tools/bench/libstar_hip_bench.so")))
-for (M, N, K) in [(8192, 8192, 8192), (843264, 2560, 320), (55296, 3840, 1280)]:
+shapes = [(8192, 8192, 8192), (843264, 2560, 320), (55296, 3840, 1280)]
+if len(sys.argv) > 3:
+    shapes = [tuple(int(v) for v in sh.split('x')) for sh in sys.argv[3].split(',')]
+for (M, N, K) in shapes:
     if fill == "zeros":
         A = torch.zeros(M, K, device="cuda", dtype=dt); W = torch.zeros(N, K, device="cuda", dtype=dt)
     elif fill == "small":
