@@ -3,6 +3,7 @@
 #include <cstdlib>
 #include "ops.h"
 #include "attn.h"
+#include "attn5.h"
 #ifdef STAR_BENCH_VARIANTS
 #include "attn_variants.h"
 #endif
@@ -27,16 +28,26 @@ static int launch_flash(Ctx* ctx, const AttnArgs& a) {
     if (!once) {
       once = true;
       int nb = -1;
-      hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, flash_attn_v3_kernel<T, 2, 1, 0, 1>, 256, 32768);
-      fprintf(stderr, "[star] flash_attn_v3<2,1,0,1>: %d workgroups of 256 threads per CU (err %d)\n", nb, (int)e);
+      hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, flash_attn_v5_kernel<T, 0>, 256, 32768);
+      fprintf(stderr, "[star] flash_attn_v5<0>: %d workgroups of 256 threads per CU (err %d)\n", nb, (int)e);
     }
   }
 #endif
-  if (a.variant == 9) {   // the shipped kernel
-    STAR_LAUNCH((flash_attn_v3_kernel<T, 2, 1, 0, 1>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);
+  if (a.variant == 9) {   // the shipped kernel (attn5.h).  Packed 16-bit row sums only where hundreds of key tiles average their
+                          // rounding out (spatial self-attention); the 77-token cross-attention keeps fp32 row sums
+    if constexpr (__is_same(T, f16)) {
+      if (a.Nk >= 1024) { STAR_LAUNCH((flash_attn_v5_kernel<T, 1>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p); return 0; }
+    }
+    STAR_LAUNCH((flash_attn_v5_kernel<T, 0>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);
     return 0;
   }
 #ifdef STAR_BENCH_VARIANTS
+  if (a.variant == 32) { STAR_LAUNCH((flash_attn_v3_kernel<T, 2, 1, 0, 1>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p); return 0; }   // the product kernel of rounds 1-2
+  if (a.variant == 30) { STAR_LAUNCH((flash_attn_v5_kernel<T, 0>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p); return 0; }
+  if (a.variant == 31) {
+    if constexpr (__is_same(T, f16)) { STAR_LAUNCH((flash_attn_v5_kernel<T, 1>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p); return 0; }
+    else return ctx->fail("flash_attn: variant 31 (packed row sums) is f16 only");
+  }
   // measured-and-lost A/B variants and ablation probes (several compute deliberately wrong results): bench build / emulator only
   if (a.variant == 0) STAR_LAUNCH((flash_attn_kernel<T>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);
   else if (a.variant == 1) STAR_LAUNCH((flash_attn_v2_kernel<T>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);

@@ -7,10 +7,12 @@
 //  temporal_attn_kernel : the per-pixel attention over the frame axis (K3;
 //      unet_v2v.py:479-489), one wavefront per (pixel, head), F <= 64.
 //
-// The product ships ONE spatial kernel, flash_attn_v3_kernel<T, 2, LAZY=1, 0, ROWSUM=1> (AttnArgs::variant 9): scale + running
-// max folded into the MFMA, lazy row maxima (the row sum of P is the overflow probe), fp32-add row sums.  The other template
-// modes of that kernel and the kernels in attn_variants.h are the measured A/B variants and ablation probes of
-// profiles/r01_attn_ab.txt; they are instantiated only in the bench build (-DSTAR_BENCH_VARIANTS) and the test emulator:
+// The product ships ONE spatial kernel, flash_attn_v5_kernel (attn5.h, AttnArgs::variant 9): the algorithm of
+// flash_attn_v3_kernel<T, 2, LAZY=1, 0, ROWSUM=1> below (scale + running max folded into the MFMA, lazy row maxima with the
+// row sum of P as overflow probe) with the non-softmax VALU taken out of the key-tile loop (+9-16 %).  The v3 kernel itself
+// (variant 32, the product of rounds 1-2), its other template modes and the kernels in attn_variants.h are the measured A/B
+// variants and ablation probes of profiles/r01_attn_ab.txt; they are instantiated only in the bench build
+// (-DSTAR_BENCH_VARIANTS) and the test emulator:
 //   2 / 3   v3 without lazy maxima (NQ = 2 / 1)      6 / 7   lazy maxima, one probe per tile / per block
 //   8       key-half pipeline      10 / 15  chunk pipeline      21 / 22  K fragments read ahead / K-V ring of three
 //   0 / 1 / 4 / 5 / 20   attn_variants.h           11-14, 16, 17  ablation probes (wrong results by construction)

@@ -174,6 +174,20 @@ STAR_DEV void glds16(const void* gsrc, void* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 #endif
 }
+// The same copy with the source split into a WAVE-UNIFORM base pointer and a 32-bit per-lane byte offset: the saddr form
+// `global_load_lds_dwordx4 v_off, s[base:base+1]`.  hipcc never selects that form for the builtin inside a loop (its loop
+// strength reduction turns base + offset into per-lane 64-bit pointers that cost 2 VGPRs and 1-2 VALU per copy and tile), so
+// it is written out; M0 carries the LDS base.  The compiler does not see this asm's vmcnt traffic: a kernel that uses it
+// must not have compiler-visible vector loads in flight around it (glds_wait() before the first call covers the prologue).
+STAR_DEV void glds16_su(const void* ubase, uint32_t lane_off, void* lds_wave_base) {
+#ifdef STAR_HOSTEMU
+  glds16((const char*)ubase + lane_off, lds_wave_base);
+#else
+  const uint32_t lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds_wave_base;
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+               :: "s"(lds), "v"(lane_off), "s"(ubase) : "memory", "m0");
+#endif
+}
 STAR_DEV void glds_wait() {
 #ifndef STAR_HOSTEMU
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -376,6 +390,17 @@ STAR_DEV float dot2_ones(vec<T, 2> a, float acc) {
     vec<f16, 2> one; one[0] = (f16)1.0f; one[1] = (f16)1.0f;
     return __builtin_amdgcn_fdot2(a, one, acc, false);
   }
+#endif
+}
+// hide a (loop-invariant) LDS address from the optimiser: it stays in its register instead of being rematerialised from its
+// terms at every use
+STAR_DEV const char* opaque(const char* p) {
+#ifndef STAR_HOSTEMU
+  auto l = (__attribute__((address_space(3))) const char*)p;
+  asm volatile("" : "+v"(l));
+  return (const char*)l;
+#else
+  return p;
 #endif
 }
 // tell the compiler a value is wave-uniform (v_readfirstlane); identity on the emulator

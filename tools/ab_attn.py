@@ -31,5 +31,12 @@ for (B, heads, N, tag) in [(8, 5, 26352, "L0"), (16, 10, 6696, "L1"), (32, 20, 1
         for v in variants:
             ctx.attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], heads, out=out, variant=v)
             o[v] = out.float().clone()
-        print("   max |v0 - v%d| = %.2e" % (variants[1], float((o[variants[0]] - o[variants[1]]).abs().max())))
+        for v in variants[1:]:
+            print("   max |v%d - v%d| = %.2e" % (variants[0], v, float((o[variants[0]] - o[v]).abs().max())))
+        if tag != "L0":   # error against an fp32 softmax(QK^T)V of the same 16-bit inputs (first frame)
+            sp = lambda t: t[:1].float().reshape(1, N, heads, 64).transpose(1, 2)
+            ref = torch.nn.functional.scaled_dot_product_attention(sp(qkv[..., :C]), sp(qkv[..., C:2 * C]), sp(qkv[..., 2 * C:])).transpose(1, 2).reshape(1, N, C)
+            for v in variants:
+                d = o[v][:1] - ref
+                print("   v%d vs fp32: rel rms %.3e  max abs %.3e" % (v, float(d.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()), float(d.abs().max())))
     del qkv, out
