@@ -20,6 +20,7 @@
 #pragma once
 #include "prim.h"
 #include "optypes.h"
+#include <type_traits>
 
 namespace star {
 
@@ -92,7 +93,14 @@ gemm_kernel(const GemmParams p) {
   const T* __restrict__ Wg = (const T*)p.W;
 
   // ---- per-thread loader state
+  // Plain operands (W always, A in A_PLAIN mode) are staged through the saddr form of the LDS-DMA (prim.h: glds16_su): a
+  // wave-uniform tile pointer that advances by 128 B per K tile on the scalar unit + a loop-invariant 32-bit lane offset;
+  // the gathered modes keep per-lane 64-bit addresses.  LDS destinations come from a uniform wave id (no v_readfirstlane).
+  const int wvu = wave_uniform(wave);
   const int pos = tid & 7;
+  uint32_t a_off[NA], w_off[NW];    // byte offsets from this tile's first A row / W row
+  const char* a_tile = (const char*)(Ag + (size_t)m0 * p.lda);
+  const char* w_tile = (const char*)(Wg + (size_t)n0 * p.K);
   // A rows handled by this thread: r_j = (j*NT + tid) >> 3
   const T* a_ptr[NA];       // PLAIN/TCONV: row base pointer (+ chunk offset)
   int a_y[NA], a_x[NA], a_f[NA];  // conv / temporal coordinates
@@ -104,8 +112,9 @@ gemm_kernel(const GemmParams p) {
     a_choff[j] = c * 8;
     int m = m0 + r;
     if (m > p.M - 1) m = p.M - 1;
+    a_off[j] = (uint32_t)((m - m0) * p.lda + c * 8) * 2u;
     if constexpr (AMODE == A_PLAIN) {
-      a_ptr[j] = Ag + (size_t)m * p.lda + c * 8;
+      a_ptr[j] = nullptr;
       a_y[j] = a_x[j] = a_f[j] = 0;
     } else if constexpr (AMODE == A_TCONV3) {
       a_ptr[j] = Ag + (size_t)m * p.lda + c * 8;
@@ -121,29 +130,31 @@ gemm_kernel(const GemmParams p) {
       a_f[j] = 0;
     }
   }
-  const T* w_ptr[NW];
 #pragma unroll
   for (int j = 0; j < NW; ++j) {
     const int r = (j * NT + tid) >> 3;
     const int c = pos ^ ((r >> 1) & 7);
     int n = n0 + r;
     if (n > p.N - 1) n = p.N - 1;
-    w_ptr[j] = Wg + (size_t)n * p.K + c * 8;
+    w_off[j] = (uint32_t)((n - n0) * p.K + c * 8) * 2u;
   }
 
   const int nk = p.K / BK;
   int tap = 0, c0 = 0;  // (tap, channel offset) of the K tile being staged
 
+  // LDS of the 2-stage loop: [A stage 0 | A stage 1 | W stage 0 | W stage 1] -- with the stage a compile-time constant of the
+  // unrolled loop, every fragment read is (loop-invariant register) + (16-bit immediate)
   auto stage = [&](int kt, int buf) {
-    char* abuf = smem + buf * STAGE;
-    char* wbuf = abuf + A_STAGE;
+    char* abuf = smem + buf * A_STAGE;
+    char* wbuf = smem + 2 * A_STAGE + buf * W_STAGE;
     int ky = 0, kx = 0;
     if constexpr (AMODE == A_CONV3X3 || AMODE == A_CONV3X3_UP) { ky = tap / 3; kx = tap - ky * 3; }
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
       const void* src;
       if constexpr (AMODE == A_PLAIN) {
-        src = a_ptr[j] + kt * BK;
+        glds16_su(a_tile + (size_t)kt * (BK * 2), a_off[j], abuf + (size_t)(j * NT + wvu * 64) * 16);
+        continue;
       } else if constexpr (AMODE == A_TCONV3) {
         const int f = a_f[j] + tap - 1;
         src = (f >= 0 && f < p.F) ? (const void*)(a_ptr[j] + (ptrdiff_t)(tap - 1) * p.HW * p.lda + c0) : p.zero_page;
@@ -157,10 +168,10 @@ gemm_kernel(const GemmParams p) {
                   ? (const void*)(a_ptr[j] + ((size_t)((yu + p.up_crop) >> 1) * p.Wd + (xu >> 1)) * p.lda + c0) : p.zero_page;
       }
       // wave-uniform LDS base: chunk q = j*NT + tid -> byte q*16 ; wave base = (j*NT + wave*64)*16
-      glds16(src, abuf + (size_t)(j * NT + wave * 64) * 16);
+      glds16(src, abuf + (size_t)(j * NT + wvu * 64) * 16);
     }
 #pragma unroll
-    for (int j = 0; j < NW; ++j) glds16(w_ptr[j] + kt * BK, wbuf + (size_t)(j * NT + wave * 64) * 16);
+    for (int j = 0; j < NW; ++j) glds16_su(w_tile + (size_t)kt * (BK * 2), w_off[j], wbuf + (size_t)(j * NT + wvu * 64) * 16);
     // advance (tap, c0)
     if constexpr (AMODE != A_PLAIN) {
       c0 += BK;
@@ -321,29 +332,37 @@ gemm_kernel(const GemmParams p) {
 #pragma unroll
       for (int j = 0; j < TN; ++j) acc[i][j] = mfma32<T>(w[j], a[i], acc[i][j]);
   };
+  // fragment addresses: row R = (wave tile row) + 32 i + frow, 16-B chunk (2 ks + fhalf) ^ ((R >> 1) & 7).  The wave-tile
+  // origins and the 32-row blocks are multiples of 16 rows, so the swizzle term depends on frow alone: one loop-invariant
+  // address per k-step and operand; stage and block go into the ds_read's immediate offset
+  static_assert(WTM % 16 == 0 && WTN % 16 == 0, "wave tiles must keep the row swizzle period");
+  const char* afb[4];
+  const char* wfb[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const int sw = ((ks * 2 + fhalf) ^ ((frow >> 1) & 7)) << 4;
+    afb[ks] = opaque(smem + (wm * WTM + frow) * 128 + sw);
+    wfb[ks] = opaque(smem + 2 * A_STAGE + (wn * WTN + frow) * 128 + sw);
+  }
   if constexpr (ABL != 4) stage(0, 0);
-  for (int kt = 0; kt < (ABL == 4 ? 0 : nk); ++kt) {
+  auto ktile = [&](int kt, auto stg) STAR_ALWAYS_INLINE {
+    constexpr int S = decltype(stg)::value;
     glds_wait();
     block_sync();
-    if (kt + 1 < nk && (ABL != 3 || kt == 0)) stage(kt + 1, (kt + 1) & 1);
+    if (kt + 1 < nk && (ABL != 3 || kt == 0)) stage(kt + 1, S ^ 1);
     if (late && kt > 0) mfma_step(af_hold, wf_hold);   // k-step 3 of the previous tile
-    const char* abuf = smem + (kt & 1) * STAGE;
-    const char* wbuf = abuf + A_STAGE;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       vec<T, 8> af[TM], wf[TN];
-      const int c = ks * 2 + fhalf;
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        const int R = wm * WTM + i * 32 + frow;
         if constexpr (ABL == 1) { for (int e = 0; e < 8; ++e) af[i][e] = from_f32<T>(0.001f * (float)(lane + i + ks)); }
-        else af[i] = *reinterpret_cast<const vec<T, 8>*>(abuf + R * 128 + ((c ^ ((R >> 1) & 7)) << 4));
+        else af[i] = *reinterpret_cast<const vec<T, 8>*>(afb[ks] + S * A_STAGE + i * 4096);
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const int R = wn * WTN + j * 32 + frow;
         if constexpr (ABL == 1) { for (int e = 0; e < 8; ++e) wf[j][e] = from_f32<T>(0.002f * (float)(lane + j + kt)); }
-        else wf[j] = *reinterpret_cast<const vec<T, 8>*>(wbuf + R * 128 + ((c ^ ((R >> 1) & 7)) << 4));
+        else wf[j] = *reinterpret_cast<const vec<T, 8>*>(wfb[ks] + S * W_STAGE + j * 4096);
       }
       if constexpr (ABL == 2) {   // keep the reads alive without MFMAs
 #pragma unroll
@@ -361,6 +380,15 @@ gemm_kernel(const GemmParams p) {
         mfma_step(af, wf);
       }
     }
+  };
+  {
+    const int nkk = (ABL == 4) ? 0 : nk;
+    int kt = 0;
+    for (; kt + 1 < nkk; kt += 2) {   // two K tiles per trip: the LDS stage is a compile-time constant in each half
+      ktile(kt, std::integral_constant<int, 0>{});
+      ktile(kt + 1, std::integral_constant<int, 1>{});
+    }
+    if (kt < nkk) ktile(kt, std::integral_constant<int, 0>{});
   }
   if (late) mfma_step(af_hold, wf_hold);
 
