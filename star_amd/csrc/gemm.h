@@ -102,32 +102,48 @@ gemm_kernel(const GemmParams p) {
   const char* a_tile = (const char*)(Ag + (size_t)m0 * p.lda);
   const char* w_tile = (const char*)(Wg + (size_t)n0 * p.K);
   // A rows handled by this thread: r_j = (j*NT + tid) >> 3
-  const T* a_ptr[NA];       // PLAIN/TCONV: row base pointer (+ chunk offset)
-  int a_y[NA], a_x[NA], a_f[NA];  // conv / temporal coordinates
-  int a_choff[NA];          // element offset of this thread's (swizzled) chunk within the 64-wide k tile
+  // Gathered A (3x3 conv, temporal conv): LDS-DMA through a buffer descriptor whose base is wave-uniform -- the first input
+  // frame this tile touches (conv) or one frame before the tile's first row (temporal conv; the three taps are then
+  // non-negative multiples of a frame) -- a loop-invariant signed lane offset g_off to the lane's tap-0 source, a 9- / 3-bit
+  // validity mask g_mask (bit = tap) and a uniform per-K-tile tap offset: two VALU adds/selects and one bit test per copy,
+  // a padding tap is an out-of-range offset that the hardware turns into zeros (prim.h: glds16_buf).  The launcher checks
+  // that the offsets stay below 2^31.  The nearest-x2 conv (A_CONV3X3_UP: 3 layers per net) keeps per-lane 64-bit addresses.
+  const T* a_ptr[NA];             // A_CONV3X3_UP: frame base pointer (+ chunk offset)
+  int a_y[NA], a_x[NA];           // A_CONV3X3_UP: upsampled-image coordinates of tap (0, 0)
+  int g_off[NA];
+  uint32_t g_mask[NA];
+  const char* g_base = (const char*)Ag;
+  if constexpr (AMODE == A_TCONV3) g_base = (const char*)(Ag + ((ptrdiff_t)m0 - p.HW) * p.lda);
+  const int g_nb0 = (AMODE == A_CONV3X3) ? m0 / (p.Ho * p.Wo) : 0;
+  if constexpr (AMODE == A_CONV3X3) g_base = (const char*)(Ag + (size_t)g_nb0 * p.H * p.Wd * p.lda);
+  const BufRsrc g_rsrc = make_rsrc(g_base, GLDS_BUF_RANGE);
 #pragma unroll
   for (int j = 0; j < NA; ++j) {
     const int r = (j * NT + tid) >> 3;
     const int c = pos ^ ((r >> 1) & 7);
-    a_choff[j] = c * 8;
     int m = m0 + r;
     if (m > p.M - 1) m = p.M - 1;
     a_off[j] = (uint32_t)((m - m0) * p.lda + c * 8) * 2u;
-    if constexpr (AMODE == A_PLAIN) {
-      a_ptr[j] = nullptr;
-      a_y[j] = a_x[j] = a_f[j] = 0;
-    } else if constexpr (AMODE == A_TCONV3) {
-      a_ptr[j] = Ag + (size_t)m * p.lda + c * 8;
-      a_f[j] = m / p.HW;
-      a_y[j] = a_x[j] = 0;
-    } else {
+    a_ptr[j] = nullptr; a_y[j] = a_x[j] = 0; g_off[j] = 0; g_mask[j] = 0;
+    if constexpr (AMODE == A_TCONV3) {
+      const int f = m / p.HW;
+      g_off[j] = (int)a_off[j];
+      g_mask[j] = (f >= 1 ? 1u : 0u) | 2u | (f + 1 < p.F ? 4u : 0u);
+    } else if constexpr (AMODE == A_CONV3X3 || AMODE == A_CONV3X3_UP) {
       const int hw = p.Ho * p.Wo;
       const int nb = m / hw, rem = m - nb * hw;
       const int yo = rem / p.Wo, xo = rem - yo * p.Wo;
       a_ptr[j] = Ag + (size_t)nb * p.H * p.Wd * p.lda + c * 8;
       a_y[j] = yo * p.stride - p.pad_t;
       a_x[j] = xo * p.stride - p.pad_l;
-      a_f[j] = 0;
+      if constexpr (AMODE == A_CONV3X3) {
+        g_off[j] = ((((nb - g_nb0) * p.H + a_y[j]) * p.Wd + a_x[j]) * p.lda + c * 8) * 2;
+#pragma unroll
+        for (int t9 = 0; t9 < 9; ++t9) {
+          const int yi = a_y[j] + t9 / 3, xi = a_x[j] + t9 % 3;
+          if (yi >= 0 && yi < p.H && xi >= 0 && xi < p.Wd) g_mask[j] |= 1u << t9;
+        }
+      }
     }
   }
 #pragma unroll
@@ -149,26 +165,25 @@ gemm_kernel(const GemmParams p) {
     char* wbuf = smem + 2 * A_STAGE + buf * W_STAGE;
     int ky = 0, kx = 0;
     if constexpr (AMODE == A_CONV3X3 || AMODE == A_CONV3X3_UP) { ky = tap / 3; kx = tap - ky * 3; }
+    // uniform byte offset of this K tile's (tap, channel block) from a lane's tap-0 source
+    int tap_off = 0;
+    if constexpr (AMODE == A_TCONV3) tap_off = (tap * p.HW * p.lda + c0) * 2;
+    if constexpr (AMODE == A_CONV3X3) tap_off = ((ky * p.Wd + kx) * p.lda + c0) * 2;
+    const uint32_t tap_bit = 1u << tap;
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
-      const void* src;
+      // wave-uniform LDS base: chunk q = j*NT + tid -> byte q*16 ; wave base = (j*NT + wave*64)*16
+      char* dst = abuf + (size_t)(j * NT + wvu * 64) * 16;
       if constexpr (AMODE == A_PLAIN) {
-        glds16_su(a_tile + (size_t)kt * (BK * 2), a_off[j], abuf + (size_t)(j * NT + wvu * 64) * 16);
-        continue;
-      } else if constexpr (AMODE == A_TCONV3) {
-        const int f = a_f[j] + tap - 1;
-        src = (f >= 0 && f < p.F) ? (const void*)(a_ptr[j] + (ptrdiff_t)(tap - 1) * p.HW * p.lda + c0) : p.zero_page;
-      } else if constexpr (AMODE == A_CONV3X3) {
-        const int yi = a_y[j] + ky, xi = a_x[j] + kx;
-        src = (yi >= 0 && yi < p.H && xi >= 0 && xi < p.Wd)
-                  ? (const void*)(a_ptr[j] + ((size_t)yi * p.Wd + xi) * p.lda + c0) : p.zero_page;
+        glds16_su(a_tile + (size_t)kt * (BK * 2), a_off[j], dst);
+      } else if constexpr (AMODE == A_TCONV3 || AMODE == A_CONV3X3) {
+        glds16_buf(g_rsrc, (g_mask[j] & tap_bit) ? (uint32_t)(g_off[j] + tap_off) : GLDS_BUF_OOB, dst);
       } else {  // A_CONV3X3_UP: conv input U[y][x] = X[(y+crop)>>1][x>>1], U is (2H-2*crop) x (2Wd)
         const int yu = a_y[j] + ky, xu = a_x[j] + kx;
-        src = (yu >= 0 && yu < 2 * p.H - 2 * p.up_crop && xu >= 0 && xu < 2 * p.Wd)
+        const void* src = (yu >= 0 && yu < 2 * p.H - 2 * p.up_crop && xu >= 0 && xu < 2 * p.Wd)
                   ? (const void*)(a_ptr[j] + ((size_t)((yu + p.up_crop) >> 1) * p.Wd + (xu >> 1)) * p.lda + c0) : p.zero_page;
+        glds16(src, dst);
       }
-      // wave-uniform LDS base: chunk q = j*NT + tid -> byte q*16 ; wave base = (j*NT + wave*64)*16
-      glds16(src, abuf + (size_t)(j * NT + wvu * 64) * 16);
     }
 #pragma unroll
     for (int j = 0; j < NW; ++j) glds16_su(w_tile + (size_t)kt * (BK * 2), w_off[j], wbuf + (size_t)(j * NT + wvu * 64) * 16);

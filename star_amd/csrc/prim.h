@@ -280,6 +280,22 @@ STAR_DEV u32x4 buf_load16(BufRsrc r, uint32_t voff) { return __builtin_amdgcn_ra
 STAR_DEV void buf_store16(BufRsrc r, uint32_t voff, u32x4 v) { __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff, 0, 0); }
 #endif
 
+// LDS-DMA through a buffer descriptor (`buffer_load_dwordx4 v_off, s[rsrc], 0 offen lds`): like glds16, but the source is
+// descriptor base + 32-bit lane offset and a lane whose offset is out of the descriptor's range writes ZEROS to its LDS
+// slot -- padding taps of the implicit-GEMM gathers need no zero page and no 64-bit address select.
+STAR_DEV void glds16_buf(BufRsrc r, uint32_t voff, void* lds_wave_base) {
+#ifdef STAR_HOSTEMU
+  struct P { void* dst; } mine{lds_wave_base};
+  (void)::star_emu::wave_exchange(&mine, sizeof(mine));
+  u32x4 v = buf_load16(r, voff);
+  memcpy((char*)lds_wave_base + lane_id() * 16, &v, 16);
+#else
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, 0, 0, 0);
+#endif
+}
+constexpr uint32_t GLDS_BUF_RANGE = 0xFFFF0000u;   // descriptor range used by the gathers: every valid offset is below it ...
+constexpr uint32_t GLDS_BUF_OOB = 0xFFFFFFF0u;     // ... and this one is outside (reads as zeros)
+
 // ---------------------------------------------------------------- transpose read
 // ds_read_b64_tr_b16: every lane passes the (8-byte aligned) LDS address of 4
 // contiguous 16-bit elements P[lane][0..3]; within each 16-lane group lane i
