@@ -21,14 +21,30 @@ static int launch_gemm_f(Ctx* ctx, const GemmArgs& a) {
   constexpr size_t smem_epi = (size_t)WM * WN * 32 * (BN / WN * 2 + 8);
   static_assert(smem_epi <= smem_loop, "the epilogue's staging blocks must fit under the bias slice");
   constexpr size_t smem = smem_loop + (size_t)BN * sizeof(float);   // + this tile's bias slice
-  dim3 grid((unsigned)(p.tiles_m * p.tiles_n)), block(WM * WN * 64);
+  unsigned nwg = (unsigned)(p.tiles_m * p.tiles_n);
+  if (a.persist > 0 && nwg > (unsigned)a.persist) nwg = (unsigned)a.persist;   // persistent tile walk (gemm.h)
+  dim3 grid(nwg), block(WM * WN * 64);
+  // 16-bit epilogue flavour (compile-time in the kernel): plain / + residual / GEGLU (plain-A layers only, no residual)
+  const bool res = !F32OUT && (a.epi & EPI_RES), geglu = !F32OUT && (a.epi & EPI_GEGLU);
+  if (geglu && (res || a.mode != A_PLAIN)) return ctx->fail("gemm: GEGLU is for plain-A layers without a residual");
+#define STAR_GEMM_GO(MODE, EF) STAR_LAUNCH((gemm_kernel<T, BM, BN, WM, WN, MODE, MINW, F32OUT, STAGGER, 0, PIPE, EF>), grid, block, smem, ctx->stream, p)
   switch (a.mode) {
-    case A_PLAIN: STAR_LAUNCH((gemm_kernel<T, BM, BN, WM, WN, A_PLAIN, MINW, F32OUT, STAGGER, 0, PIPE>), grid, block, smem, ctx->stream, p); break;
-    case A_CONV3X3: STAR_LAUNCH((gemm_kernel<T, BM, BN, WM, WN, A_CONV3X3, MINW, F32OUT, STAGGER, 0, PIPE>), grid, block, smem, ctx->stream, p); break;
-    case A_CONV3X3_UP: STAR_LAUNCH((gemm_kernel<T, BM, BN, WM, WN, A_CONV3X3_UP, MINW, F32OUT, STAGGER, 0, PIPE>), grid, block, smem, ctx->stream, p); break;
-    case A_TCONV3: STAR_LAUNCH((gemm_kernel<T, BM, BN, WM, WN, A_TCONV3, MINW, F32OUT, STAGGER, 0, PIPE>), grid, block, smem, ctx->stream, p); break;
+    case A_PLAIN:
+      if constexpr (F32OUT) STAR_GEMM_GO(A_PLAIN, 0);
+      else { if (geglu) STAR_GEMM_GO(A_PLAIN, 2); else if (res) STAR_GEMM_GO(A_PLAIN, 1); else STAR_GEMM_GO(A_PLAIN, 0); }
+      break;
+    case A_CONV3X3:
+      if constexpr (F32OUT) STAR_GEMM_GO(A_CONV3X3, 0); else { if (res) STAR_GEMM_GO(A_CONV3X3, 1); else STAR_GEMM_GO(A_CONV3X3, 0); }
+      break;
+    case A_CONV3X3_UP:
+      if constexpr (F32OUT) STAR_GEMM_GO(A_CONV3X3_UP, 0); else { if (res) STAR_GEMM_GO(A_CONV3X3_UP, 1); else STAR_GEMM_GO(A_CONV3X3_UP, 0); }
+      break;
+    case A_TCONV3:
+      if constexpr (F32OUT) STAR_GEMM_GO(A_TCONV3, 0); else { if (res) STAR_GEMM_GO(A_TCONV3, 1); else STAR_GEMM_GO(A_TCONV3, 0); }
+      break;
     default: return ctx->fail("gemm: bad A mode");
   }
+#undef STAR_GEMM_GO
   return 0;
 }
 
@@ -72,6 +88,12 @@ static int launch_gemm8(Ctx* ctx, const GemmArgs& a, int grid_cap) {
 template <class T>
 static int launch_gemm(Ctx* ctx, const GemmArgs& a) {
   int tile = a.force_tile;
+  if (tile >= 100 && tile < 1000) {   // A/B: 1xx = tile xx walked by 256 persistent workgroups, 2xx by 512
+    GemmArgs b = a;
+    b.force_tile = tile % 100;
+    b.persist = 256 * (tile / 100);
+    return launch_gemm<T>(ctx, b);
+  }
   if (!tile) {
     const bool geglu = (a.epi & EPI_GEGLU) != 0;
     if (a.M <= 4096 && a.N <= 1024) tile = 3;                          // small problems: more, smaller tiles

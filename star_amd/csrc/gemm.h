@@ -42,18 +42,28 @@ struct GemmParams {
   int tiles_m, tiles_n;
 };
 
-// exact (erf) GELU, F.gelu default (unet_v2v.py:504).  erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below
-// the 16-bit output rounding): one exp2, one rcp and a 5-term Horner instead of libm's branchy erff in the GEGLU epilogue.
+// exact (erf) GELU, F.gelu default (unet_v2v.py:504): gelu(x) = max(x, 0) - |x| q(|x|), q(t) = 0.5 erfc(t / sqrt 2).
+// log2 q is smooth and nearly quadratic, so q = exp2(P7(z)), z = min(|x| / sqrt 2, 4.5), with a degree-7 polynomial fitted on
+// Chebyshev nodes of [0, 4.5]: |relative error of q| <= 4e-6 everywhere, i.e. the NEGATIVE TAIL of gelu keeps its relative
+// accuracy (6e-6; beyond z = 4.5 |gelu| < 7e-10, below the 16-bit denormals) and the absolute error is <= 6e-7 (fp32
+// evaluation, checked against float64 on 4e5 points of [-8, 8]) -- far below the 16-bit output rounding.  One transcendental
+// and 11 plain VALU per element instead of the Abramowitz-Stegun 7.1.26 form's rcp + exp2 + ~18 (whose 1 - erf cancellation
+// also loses the tail): the GEGLU epilogue of the short-K feed-forward layers is VALU-bound.
 STAR_DEV float gelu_erf(float x) {
-  const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = fast_rcp(1.0f + 0.3275911f * z);
-  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-  const float erf_abs = 1.0f - poly * fast_exp2(-1.4426950408889634f * z * z);
-  const float erf_x = x < 0.f ? -erf_abs : erf_abs;
-  return 0.5f * x * (1.0f + erf_x);
+  const float ax = fabsf(x);
+  const float z = fminf(ax * 0.70710678118654752440f, 4.5f);
+  float p = -2.045475840e-05f;
+  p = p * z + 4.882977128e-04f;
+  p = p * z + -5.237886925e-03f;
+  p = p * z + 3.395745580e-02f;
+  p = p * z + -1.525140382e-01f;
+  p = p * z + -9.170034400e-01f;
+  p = p * z + -1.628095626e+00f;
+  p = p * z + -9.999960965e-01f;
+  return fmaxf(x, 0.f) - ax * fast_exp2(p);
 }
 
-template <class T, int BM, int BN, int WM, int WN, int AMODE, int MINW, bool F32OUT, bool STAGGER, int ABL = 0, int PIPE = 0>  // ABL: ablation probes (bench only); PIPE: ring slots of the pipelined loop (0 = 2-stage loop)
+template <class T, int BM, int BN, int WM, int WN, int AMODE, int MINW, bool F32OUT, bool STAGGER, int ABL = 0, int PIPE = 0, int EPIF = 0>  // ABL: ablation probes (bench only); PIPE: ring slots of the pipelined loop (0 = 2-stage loop); EPIF: 16-bit epilogue flavour (bit 0 residual add, bit 1 GEGLU)
 STAR_GLOBAL void STAR_LAUNCH_BOUNDS(WM * WN * 64, MINW)
 gemm_kernel(const GemmParams p) {
   constexpr int NT = WM * WN * 64;
@@ -68,14 +78,20 @@ gemm_kernel(const GemmParams p) {
   constexpr int SMEM_LOOP = PIPE ? PIPE * (BM + BN) * 64 : 2 * STAGE;   // bytes of the main loop's buffers; bias[BN] fp32 follows
 
   char* smem = dyn_smem();
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
 
   // ---- XCD-aware tile order: blocks that run on one XCD (bid % 8) walk consecutive
   // logical tile ids, and consecutive ids share the A row panel (different n tile).
+  // Persistent tile walk: the launcher may start fewer workgroups than output tiles (a multiple of 8, so a workgroup's
+  // tiles stay on its XCD); workgroup b then computes tiles b, b + gridDim.x, ...  The global stores of one tile drain while
+  // the next tile's K loop runs, and there is no workgroup turnover between them.  (The body below is not re-indented.)
   const int nblk = p.tiles_m * p.tiles_n;
-  int bid = blockIdx.x;
+  for (int pb = blockIdx.x; pb < nblk; pb += gridDim.x) {
+  // the thread id is re-read opaquely per tile: otherwise hipcc hoists every lane-derived address term out of the tile loop
+  // and spills 50-120 registers to keep them alive across the whole body
+  const int tid = opaque_int((int)threadIdx.x);
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  int bid = pb;
   {
     const int q = nblk >> 3, r = nblk & 7;
     const int xcd = bid & 7, slot = bid >> 3;
@@ -443,57 +459,62 @@ gemm_kernel(const GemmParams p) {
     // the write stream: no global load is ever issued behind a store (vmcnt retires in order, a load behind stores waits
     // for their HBM write latency) -- the bias comes from LDS, the residual chunks of a 32-row block are all read before
     // the first store of the previous block is issued -- and the barriers between the staging steps do not drain vmcnt.
-    const bool geglu = (p.epi & EPI_GEGLU) != 0;
-    const int out_wtn = geglu ? WTN / 2 : WTN;       // output columns per wave
-    const int out_n0 = geglu ? (n0 + wn * WTN) / 2 : (n0 + wn * WTN);
-    const int N_out = geglu ? p.N / 2 : p.N;
+    // Residual / GEGLU are compile-time (EPIF: bit 0 residual, bit 1 GEGLU): every index below folds to constants, the
+    // residual registers exist only where a residual is added, and the residual loads are unconditional (rows and columns
+    // clamped into the matrix instead of exec-masked), so nothing of the epilogue stays live across the K loop.
+    constexpr bool RESF = (EPIF & 1) != 0, GEGLUF = (EPIF & 2) != 0;
+    constexpr int out_wtn = GEGLUF ? WTN / 2 : WTN;   // output columns per wave
+    const int out_n0 = GEGLUF ? (n0 + wn * WTN) / 2 : (n0 + wn * WTN);
+    const int N_out = GEGLUF ? p.N / 2 : p.N;
     constexpr int pitch = WTN * 2 + 8;                // bytes; (pitch/4) % 4 == 2 -> conflict-free b64 writes
-    constexpr int RUN = (4 * WTN + 63) / 64;          // 16-B chunks per lane and 32-row block
+    constexpr int cpr = out_wtn / 8;                  // 16-B chunks per row
+    constexpr int nchunks = 32 * cpr;
+    static_assert(nchunks % 64 == 0, "a 32-row block must split evenly over the lanes");
+    constexpr int RUN = nchunks / 64;                 // 16-B chunks per lane and 32-row block
     const float* bias_lds = reinterpret_cast<const float*>(smem + SMEM_LOOP) + wn * WTN;
     block_sync();                                     // all MFMA reads of the stages are done
     char* my = smem + wave * (32 * pitch);
-    const int cpr = out_wtn / 8;                      // 16-B chunks per row
-    const int nchunks = 32 * cpr;
 
-    vec<T, 8> rv[TM][RUN];
-    auto load_res = [&](int i) {
+    vec<T, 8> rv[RESF ? TM : 1][RESF ? RUN : 1];
+    auto load_res = [&](int i) STAR_ALWAYS_INLINE {
+      if constexpr (RESF) {
 #pragma unroll
-      for (int u = 0; u < RUN; ++u) {
-        const int q = lane + 64 * u;
-        const int row = q / cpr, cc = q - row * cpr;
-        const int m = m0 + wm * WTM + i * 32 + row, n = out_n0 + cc * 8;
-        if (q < nchunks && m < p.M && n < N_out)
+        for (int u = 0; u < RUN; ++u) {
+          const int q = lane + 64 * u;
+          const int row = q / cpr, cc = q - row * cpr;
+          int m = m0 + wm * WTM + i * 32 + row, n = out_n0 + cc * 8;
+          if (m > p.M - 1) m = p.M - 1;
+          if (n > N_out - 8) n = N_out - 8;
           rv[i][u] = *reinterpret_cast<const vec<T, 8>*>((const T*)p.res + (size_t)m * p.ldr + n);
-      }
-    };
-    auto store_block = [&](int i) {
-#pragma unroll
-      for (int u = 0; u < RUN; ++u) {
-        const int q = lane + 64 * u;
-        const int row = q / cpr, cc = q - row * cpr;
-        const int m = m0 + wm * WTM + i * 32 + row, n = out_n0 + cc * 8;
-        if (q < nchunks && m < p.M && n < N_out) {
-          const vec<T, 4> lo = *reinterpret_cast<const vec<T, 4>*>(my + row * pitch + cc * 16);
-          const vec<T, 4> hi = *reinterpret_cast<const vec<T, 4>*>(my + row * pitch + cc * 16 + 8);
-          vec<T, 8> ov;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { ov[e] = lo[e]; ov[4 + e] = hi[e]; }
-          if (p.epi & EPI_RES) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) ov[e] = from_f32<T>(to_f32<T>(ov[e]) + to_f32<T>(rv[i][u][e]));
-          }
-          if (ABL != 5 || p.M < 0) *reinterpret_cast<vec<T, 8>*>((T*)p.C + (size_t)m * p.ldc + n) = ov;
         }
       }
     };
+    auto store_block = [&](int i) STAR_ALWAYS_INLINE {
+#pragma unroll
+      for (int u = 0; u < RUN; ++u) {
+        const int q = lane + 64 * u;
+        const int row = q / cpr, cc = q - row * cpr;
+        const int m = m0 + wm * WTM + i * 32 + row, n = out_n0 + cc * 8;
+        const vec<T, 4> lo = *reinterpret_cast<const vec<T, 4>*>(my + row * pitch + cc * 16);
+        const vec<T, 4> hi = *reinterpret_cast<const vec<T, 4>*>(my + row * pitch + cc * 16 + 8);
+        vec<T, 8> ov;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ov[e] = lo[e]; ov[4 + e] = hi[e]; }
+        if constexpr (RESF) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ov[e] = from_f32<T>(to_f32<T>(ov[e]) + to_f32<T>(rv[i][u][e]));
+        }
+        if (m < p.M && n < N_out && (ABL != 5 || p.M < 0)) *reinterpret_cast<vec<T, 8>*>((T*)p.C + (size_t)m * p.ldc + n) = ov;
+      }
+    };
 
-    if (p.epi & EPI_RES) load_res(0);
+    load_res(0);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       // ---- registers -> LDS (T, row-major [32][out_wtn])
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        if (geglu && (j & 1)) continue;
+        if (GEGLUF && (j & 1)) continue;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int nl = j * 32 + 8 * g + 4 * fhalf;  // local n within the wave tile (pre-GEGLU)
@@ -502,7 +523,7 @@ gemm_kernel(const GemmParams p) {
           for (int e = 0; e < 4; ++e) v[e] = acc[i][j][g * 4 + e];
           v += *reinterpret_cast<const f32x4*>(bias_lds + nl);   // zeros when the layer has no bias
           int ncol = nl;
-          if (geglu) {
+          if constexpr (GEGLUF) {
             f32x4 gt;
 #pragma unroll
             for (int e = 0; e < 4; ++e) gt[e] = acc[i][(j + 1 < TN) ? j + 1 : j][g * 4 + e];
@@ -518,12 +539,14 @@ gemm_kernel(const GemmParams p) {
         }
       }
       barrier_keep_dma();
-      if ((p.epi & EPI_RES) && i + 1 < TM) load_res(i + 1);   // the next block's residual, ahead of this block's stores
+      if (i + 1 < TM) load_res(i + 1);   // the next block's residual, ahead of this block's stores
       // ---- LDS -> global: whole 16-B chunks along rows (+ residual, already in registers)
       store_block(i);
       barrier_keep_dma();
     }
   }
+  if constexpr (F32OUT) block_sync();   // the next tile's LDS-DMA must not overtake this tile's last fragment reads
+  }   // persistent tile walk
 }
 
 }  // namespace star

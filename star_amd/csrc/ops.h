@@ -29,6 +29,7 @@ struct GemmArgs {
   int up_crop = 1;
   int epi = 0;
   int force_tile = 0;  // 0 = auto; 1 = 256x256, 2 = 256x320, 3 = 128x128, 4 = 256x128 (tests)
+  int persist = 0;     // > 0: at most this many workgroups walk the output tiles (multiple of 8); 0 = one workgroup per tile
 };
 int op_gemm(Ctx* ctx, const GemmArgs& a);
 

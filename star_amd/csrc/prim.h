@@ -419,6 +419,15 @@ STAR_DEV const char* opaque(const char* p) {
   return p;
 #endif
 }
+// an integer the optimiser cannot see through (blocks loop-invariant code motion of everything derived from it)
+STAR_DEV int opaque_int(int v) {
+#ifdef STAR_HOSTEMU
+  asm volatile("" : "+r"(v));
+#else
+  asm volatile("" : "+v"(v));
+#endif
+  return v;
+}
 // tell the compiler a value is wave-uniform (v_readfirstlane); identity on the emulator
 STAR_DEV int wave_uniform(int v) {
 #ifdef STAR_HOSTEMU
