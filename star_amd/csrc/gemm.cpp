@@ -98,7 +98,9 @@ static int launch_gemm(Ctx* ctx, const GemmArgs& a) {
     const bool geglu = (a.epi & EPI_GEGLU) != 0;
     if (a.M <= 4096 && a.N <= 1024) tile = 3;                          // small problems: more, smaller tiles
     else if (!geglu && a.N % 320 == 0) tile = 2;                        // 320 / 640 / 960 / 1280 / 1920-wide layers
-    else if (geglu && a.K <= 320 && a.mode == A_PLAIN) tile = 9;        // short K, GELU-heavy epilogue: two workgroups per CU overlap it
+    // (rounds 1-2 sent the short-K GEGLU layers to tile 9, two 4-wave workgroups per CU hiding each other's GELU epilogue;
+    // with the erfc-form GELU and the compile-time epilogue the 8-wave 256x256 tile is 7 % faster there: 1.89 vs 2.04 ms at
+    // 843264 x 2560 x 320, profiles/r02_gemm_tiles_after_valu.txt)
     else if (a.N <= 128) tile = 4;
     else tile = 1;
   }
