@@ -153,6 +153,24 @@ int star_vae_encode(star_ctx* ctx, const float* x, float* moments, int32_t n, in
 int star_vae_decode(star_ctx* ctx, const float* z, float* out, int32_t n, int32_t h, int32_t w);
 int star_softmax_rows(star_ctx* ctx, const float* s, int32_t lds, void* p, int32_t ldp, int32_t rows, int32_t n, float scale);
 
+/* ---- CogVideoX-5B DiT block (STAR's CogVideoX variant, cogvideox-based/sat) ------------------ */
+typedef struct star_dit_config {
+  int32_t hidden, heads, time_embed_dim, n_layers;   /* 3072, 48, 512, 42 at full size; head dim is 64 */
+  float ln_eps;                                       /* sat layernorm_epsilon (1e-5) */
+} star_dit_config;
+/* build from staged tensors named as the SAT checkpoint under `model.diffusion_model.`:
+ * transformer.layers.{i}.{input_layernorm, post_attention_layernorm, attention.query_key_value, attention.dense,
+ * mlp.dense_h_to_4h, mlp.dense_4h_to_h}.{weight,bias}, transformer.layers.{i}.{spa_local,temp_local}.conv1.weight (the LIEM gates
+ * of cogvideox-based/transformer.py:316-348,485-486) and mixins.adaln_layer.{adaLN_modulations.{i}.1, query_layernorm_list.{i},
+ * key_layernorm_list.{i}}.{weight,bias} */
+int star_dit_build(star_ctx* ctx, const star_dit_config* cfg);
+/* replaces: AdaLNMixin.layer_forward (cogvideox-based/sat/dit_video_concat.py:482-563) for layer `layer`, with the 3-D rotary
+ * embedding (:254-346) and the QK LayerNorm (:571-598) inside its attention.  hidden_in / hidden_out: device rows
+ * [text_len + T*H*W][hidden] in the context's storage dtype (text tokens first, video tokens in (t h w) order, batch 1);
+ * emb: fp32 device [time_embed_dim], the timestep embedding kwargs["emb"]. */
+int star_dit_block_forward(star_ctx* ctx, int32_t layer, const void* hidden_in, const float* emb, void* hidden_out,
+                           int32_t text_len, int32_t T, int32_t H, int32_t W);
+
 /* ---- full-resolution frame kernels either side of the diffusion path ---------- */
 /* replaces: F.interpolate(video_data, [target_h, target_w], mode='bilinear') + F.pad(video_data, padding, 'constant', 1)
  * in VideoToVideo_sr.test (video_to_video_model.py:81-87).  src: fp32 device planes x [h][w] (planes = F*3);

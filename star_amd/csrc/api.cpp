@@ -8,6 +8,11 @@
 #include <cstdlib>
 
 using namespace star;
+namespace star {
+int dit_build(Ctx* ctx, int D, int heads, int E, int n_layers, float ln_eps);
+int dit_block_forward(Ctx* ctx, int layer, const void* x_in, const float* emb, void* x_out, int text_len, int T, int H, int W);
+void dit_release(Ctx* ctx);
+}
 
 struct star_ctx { Ctx c; };
 
@@ -75,6 +80,7 @@ void star_ctx_destroy(star_ctx* h) {
   rt::stream_sync(h->c.stream);
   h->c.unet.reset();
   h->c.vae.reset();
+  dit_release(&h->c);
   h->c.pool.release();
   if (h->c.zero_page) rt::dev_free(h->c.zero_page);
   delete h;
@@ -237,6 +243,17 @@ int star_vae_encode(star_ctx* h, const float* x, float* moments, int32_t n, int3
 int star_vae_decode(star_ctx* h, const float* z, float* out, int32_t n, int32_t hh, int32_t w) {
   if (h) rt::set_device(h->c.device);
   return finish(h, vae_decode(&h->c, z, out, n, hh, w));
+}
+int star_dit_build(star_ctx* h, const star_dit_config* c) {
+  if (!h || !c) return -1;
+  rt::set_device(h->c.device);
+  return finish(h, dit_build(&h->c, c->hidden, c->heads, c->time_embed_dim, c->n_layers, c->ln_eps));
+}
+int star_dit_block_forward(star_ctx* h, int32_t layer, const void* hidden_in, const float* emb, void* hidden_out, int32_t text_len,
+                           int32_t T, int32_t H, int32_t W) {
+  if (!h) return -1;
+  rt::set_device(h->c.device);
+  return finish(h, dit_block_forward(&h->c, layer, hidden_in, emb, hidden_out, text_len, T, H, W));
 }
 int star_softmax_rows(star_ctx* h, const float* s, int32_t lds, void* p, int32_t ldp, int32_t rows, int32_t n, float scale) {
   if (h) rt::set_device(h->c.device);   // follow the context's device, not the caller's current one

@@ -25,13 +25,13 @@ static int launch_gemm_f(Ctx* ctx, const GemmArgs& a) {
   if (a.persist > 0 && nwg > (unsigned)a.persist) nwg = (unsigned)a.persist;   // persistent tile walk (gemm.h)
   dim3 grid(nwg), block(WM * WN * 64);
   // 16-bit epilogue flavour (compile-time in the kernel): plain / + residual / GEGLU (plain-A layers only, no residual)
-  const bool res = !F32OUT && (a.epi & EPI_RES), geglu = !F32OUT && (a.epi & EPI_GEGLU);
-  if (geglu && (res || a.mode != A_PLAIN)) return ctx->fail("gemm: GEGLU is for plain-A layers without a residual");
+  const bool res = !F32OUT && (a.epi & EPI_RES), geglu = !F32OUT && (a.epi & EPI_GEGLU), gelut = !F32OUT && (a.epi & EPI_GELU_TANH);
+  if ((geglu || gelut) && (res || a.mode != A_PLAIN || (geglu && gelut))) return ctx->fail("gemm: GEGLU / tanh-GELU are for plain-A layers without a residual");
 #define STAR_GEMM_GO(MODE, EF) STAR_LAUNCH((gemm_kernel<T, BM, BN, WM, WN, MODE, MINW, F32OUT, STAGGER, 0, PIPE, EF>), grid, block, smem, ctx->stream, p)
   switch (a.mode) {
     case A_PLAIN:
       if constexpr (F32OUT) STAR_GEMM_GO(A_PLAIN, 0);
-      else { if (geglu) STAR_GEMM_GO(A_PLAIN, 2); else if (res) STAR_GEMM_GO(A_PLAIN, 1); else STAR_GEMM_GO(A_PLAIN, 0); }
+      else { if (geglu) STAR_GEMM_GO(A_PLAIN, 2); else if (gelut) STAR_GEMM_GO(A_PLAIN, 4); else if (res) STAR_GEMM_GO(A_PLAIN, 1); else STAR_GEMM_GO(A_PLAIN, 0); }
       break;
     case A_CONV3X3:
       if constexpr (F32OUT) STAR_GEMM_GO(A_CONV3X3, 0); else { if (res) STAR_GEMM_GO(A_CONV3X3, 1); else STAR_GEMM_GO(A_CONV3X3, 0); }
@@ -162,7 +162,7 @@ int op_gemm(Ctx* ctx, const GemmArgs& a) {
   if (a.lda % 8 != 0) return ctx->fail("gemm: lda must be a multiple of 8");
   if (a.mode != A_PLAIN && a.Cin % 64 != 0) return ctx->fail("gemm: conv Cin must be a multiple of 64");
   if ((a.epi & EPI_GEGLU) && (a.N % 64 != 0)) return ctx->fail("gemm: GEGLU needs N % 64 == 0");
-  if ((a.epi & EPI_GEGLU) && (a.epi & EPI_OUT_F32)) return ctx->fail("gemm: GEGLU with fp32 output is not supported");
+  if ((a.epi & (EPI_GEGLU | EPI_GELU_TANH)) && (a.epi & EPI_OUT_F32)) return ctx->fail("gemm: GEGLU / GELU with fp32 output is not supported");
   if (a.epi & EPI_OUT_F32) {
     if (a.N % 4 || a.ldc % 4 || ((a.epi & EPI_RES) && a.ldr % 4)) return ctx->fail("gemm: fp32 output needs N, ldc (and ldr) multiples of 4");
   } else {

@@ -63,7 +63,13 @@ STAR_DEV float gelu_erf(float x) {
   return fmaxf(x, 0.f) - ax * fast_exp2(p);
 }
 
-template <class T, int BM, int BN, int WM, int WN, int AMODE, int MINW, bool F32OUT, bool STAGGER, int ABL = 0, int PIPE = 0, int EPIF = 0>  // ABL: ablation probes (bench only); PIPE: ring slots of the pipelined loop (0 = 2-stage loop); EPIF: 16-bit epilogue flavour (bit 0 residual add, bit 1 GEGLU)
+// tanh-form GELU (sat.mpu.utils.gelu_impl: 0.5 x (1 + tanh(0.79788456 x (1 + 0.044715 x^2)))) = x sigmoid(2 u)
+STAR_DEV float gelu_tanh(float x) {
+  const float u = 0.7978845608028654f * x * (1.0f + 0.044715f * x * x);
+  return x * fast_rcp(1.0f + fast_exp2(-2.8853900817779268f * u));
+}
+
+template <class T, int BM, int BN, int WM, int WN, int AMODE, int MINW, bool F32OUT, bool STAGGER, int ABL = 0, int PIPE = 0, int EPIF = 0>  // ABL: ablation probes (bench only); PIPE: ring slots of the pipelined loop (0 = 2-stage loop); EPIF: 16-bit epilogue flavour (bit 0 residual add, bit 1 GEGLU, bit 2 tanh-GELU)
 STAR_GLOBAL void STAR_LAUNCH_BOUNDS(WM * WN * 64, MINW)
 gemm_kernel(const GemmParams p) {
   constexpr int NT = WM * WN * 64;
@@ -462,7 +468,7 @@ gemm_kernel(const GemmParams p) {
     // Residual / GEGLU are compile-time (EPIF: bit 0 residual, bit 1 GEGLU): every index below folds to constants, the
     // residual registers exist only where a residual is added, and the residual loads are unconditional (rows and columns
     // clamped into the matrix instead of exec-masked), so nothing of the epilogue stays live across the K loop.
-    constexpr bool RESF = (EPIF & 1) != 0, GEGLUF = (EPIF & 2) != 0;
+    constexpr bool RESF = (EPIF & 1) != 0, GEGLUF = (EPIF & 2) != 0, GELUTF = (EPIF & 4) != 0;
     constexpr int out_wtn = GEGLUF ? WTN / 2 : WTN;   // output columns per wave
     const int out_n0 = GEGLUF ? (n0 + wn * WTN) / 2 : (n0 + wn * WTN);
     const int N_out = GEGLUF ? p.N / 2 : p.N;
@@ -531,6 +537,10 @@ gemm_kernel(const GemmParams p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = v[e] * gelu_erf(gt[e]);
             ncol = (j >> 1) * 32 + 8 * g + 4 * fhalf;
+          }
+          if constexpr (GELUTF) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
           }
           vec<T, 4> o;
 #pragma unroll
