@@ -163,13 +163,14 @@ def main():
         a = prof_u["attn_self"]
         l0_flops = a["max_flops"]                       # the largest launches = the L0 layers (N = H*W of the padded latent)
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_attn_traffic.json")
+        tname = "r02_attn_v5_traffic.json"
+        tpath = os.path.join(ROOT, "profiles", tname)
         if os.path.isfile(tpath) and not args.small and args.config in ("cfg2", "cfg3") and not custom:   # PMC pass of the same kernel at the same shape
             traffic = json.load(open(tpath))["traffic_bytes_per_launch"]
-        roof = {"bound": "mfma", "kernel": "flash_attn_v3_kernel (spatial self-attention, d=64)", "unit": "TFLOP/s",
+        roof = {"bound": "mfma", "kernel": "flash_attn_v5_kernel (spatial self-attention, d=64)", "unit": "TFLOP/s",
                 "achieved": (l0_flops / (a["max_flops_ms"] * 1e-3) / 1e12) if a["max_flops_ms"] else None,
                 "peak": PEAK_BF16_MFMA / 1e12, "traffic": traffic,
-                "traffic_source": "profiles/r01_attn_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch)" if traffic else None,
+                "traffic_source": f"profiles/{tname} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch)" if traffic else None,
                 "algorithmic_flops_per_launch": l0_flops, "avg_launch_ms": a["max_flops_ms"],
                 "all_self_attn_launches": {"launches": a["launches"], "ms": a["ms"], "TFLOP/s": a["flops"] / max(a["ms"], 1e-9) / 1e9}}
         roof["frac"] = roof["achieved"] / roof["peak"] if roof["achieved"] else None

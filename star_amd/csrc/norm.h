@@ -28,8 +28,12 @@ STAR_GLOBAL void gn_stats_kernel(const GnStatsParams p) {
   const int CC8 = p.C >> 3;
   const int RL = blockDim.x / CC8;
   const int cc = t % CC8, rl = t / CC8;
-  const int stat = blockIdx.y;
-  const int r0 = blockIdx.x * p.slab;
+  // The statistics pass walks the tensor BACKWARDS (the first workgroups take the last rows): the producer wrote x front to
+  // back, so its tail is what the 256 MB Infinity Cache still holds, and the apply pass, which runs front to back, then finds
+  // the head this pass read last.  Slab indices (and with them the reduction order and the results) are unchanged.
+  const int stat = (int)gridDim.y - 1 - (int)blockIdx.y;
+  const int slab_id = (int)gridDim.x - 1 - (int)blockIdx.x;
+  const int r0 = slab_id * p.slab;
   int r1 = r0 + p.slab;
   if (r1 > p.rows_per_stat) r1 = p.rows_per_stat;
   float s[8], ss[8];
@@ -67,7 +71,7 @@ STAR_GLOBAL void gn_stats_kernel(const GnStatsParams p) {
         b += (double)q[8 + e];
       }
     }
-    double* out = p.partial + (((size_t)stat * gridDim.x + blockIdx.x) * 32 + t) * 2;
+    double* out = p.partial + (((size_t)stat * gridDim.x + slab_id) * 32 + t) * 2;
     out[0] = a;
     out[1] = b;
   }
