@@ -117,8 +117,11 @@ static int launch_gemm(Ctx* ctx, const GemmArgs& a) {
     case 7: return launch_gemm_t<T, 256, 256, 4, 2, 2, false, 4>(ctx, a);   // pipelined main loop (ring of 4 x 32-k slots)
     case 8: return launch_gemm_t<T, 256, 320, 4, 2, 2, false, 4>(ctx, a);
     case 14: return launch_gemm_t<T, 256, 256, 2, 2, 1>(ctx, a);   // 4 waves x (128 x 128), one wave per SIMD, accumulators in AGPRs: 1/3 fewer LDS fragment reads
-    case 10: return launch_gemm_t<T, 128, 320, 2, 2, 2, false, 2>(ctx, a);
 #endif
+    // two independent 4-wave workgroups per CU on a 128 x 320 tile (two 32-deep LDS slots, 56 KB each): one group's prologue /
+    // epilogue / store drain runs beside the other's MFMAs -- for the short-K layers, whose tiles spend most of their time
+    // outside the K loop
+    case 10: return launch_gemm_t<T, 128, 320, 2, 2, 2, false, 2>(ctx, a);
     // two independent 4-wave workgroups per CU (72 KB of LDS each): one group's epilogue and DMA latency hide behind the
     // other group's MFMA burst (auto-selected for the short-K GEGLU layers)
     case 9: return launch_gemm_t<T, 128, 256, 2, 2, 2, false, 3>(ctx, a);

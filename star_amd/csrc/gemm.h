@@ -259,14 +259,23 @@ gemm_kernel(const GemmParams p) {
         pa_y[i] = yo * p.stride - p.pad_t; pa_x[i] = xo * p.stride - p.pad_l; pa_f[i] = 0;
       }
     }
-    const T* pw_ptr[LW0 + 1];
+    // plain operands through the saddr LDS-DMA (uniform tile pointer + loop-invariant 32-bit lane offset), as in the 2-stage loop
+    uint32_t pa_off[LA], pw_off[LW0 + 1];
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+      const int r = (64 * (wv + NWV * i) + lane) >> 2;
+      const int c = lpos ^ ((r >> 2) & 3);
+      int m = m0 + r;
+      if (m > p.M - 1) m = p.M - 1;
+      pa_off[i] = (uint32_t)((m - m0) * p.lda + c * 8) * 2u;
+    }
 #pragma unroll
     for (int i = 0; i < LW0 + 1; ++i) {
       const int r = (64 * (wv + NWV * i) + lane) >> 2;
       const int c = lpos ^ ((r >> 2) & 3);
       int n = n0 + r;
       if (n > p.N - 1) n = p.N - 1;
-      pw_ptr[i] = Wg + (size_t)n * p.K + c * 8;
+      pw_off[i] = (uint32_t)((n - n0) * p.K + c * 8) * 2u;
     }
     const int nsteps = p.K / 32;
     int ptap = 0, pc0 = 0;
@@ -279,7 +288,7 @@ gemm_kernel(const GemmParams p) {
 #pragma unroll
       for (int i = 0; i < LA; ++i) {
         const void* src;
-        if constexpr (AMODE == A_PLAIN) src = pa_ptr[i] + s_ * 32;
+        if constexpr (AMODE == A_PLAIN) { glds16_su(a_tile + (size_t)s_ * 64, pa_off[i], abuf + (size_t)(wv + NWV * i) * 1024); continue; }
         else if constexpr (AMODE == A_TCONV3) {
           const int f = pa_f[i] + ptap - 1;
           src = (f >= 0 && f < p.F) ? (const void*)(pa_ptr[i] + (ptrdiff_t)(ptap - 1) * p.HW * p.lda + pc0) : p.zero_page;
@@ -294,8 +303,8 @@ gemm_kernel(const GemmParams p) {
         glds16(src, abuf + (size_t)(wv + NWV * i) * 1024);
       }
 #pragma unroll
-      for (int i = 0; i < LW0; ++i) glds16(pw_ptr[i] + s_ * 32, wbuf + (size_t)(wv + NWV * i) * 1024);
-      if (WX > 0 && wextra) glds16(pw_ptr[LW0] + s_ * 32, wbuf + (size_t)(wv + NWV * LW0) * 1024);
+      for (int i = 0; i < LW0; ++i) glds16_su(w_tile + (size_t)s_ * 64, pw_off[i], wbuf + (size_t)(wv + NWV * i) * 1024);
+      if (WX > 0 && wextra) glds16_su(w_tile + (size_t)s_ * 64, pw_off[LW0], wbuf + (size_t)(wv + NWV * LW0) * 1024);
       if constexpr (AMODE != A_PLAIN) { pc0 += 32; if (pc0 >= p.Cin) { pc0 = 0; ++ptap; } }
     };
     // wait until at most `steps_in_flight` K steps of this wave's DMA are outstanding
@@ -324,25 +333,27 @@ gemm_kernel(const GemmParams p) {
       wait_steps(ahead);
     }
     barrier_keep_dma();
-    int rslot = 0, islot = PIPE - 1;                    // ring slot being read / to be filled next
-    for (int st = 0; st < nsteps; ++st) {
-      if (st + PIPE - 1 < nsteps) issue(st + PIPE - 1, islot);   // that slot was read in step st-1: every wave is past its barrier
-      const char* abuf = smem + rslot * SLOT;
-      const char* wbuf = abuf + BM * 64;
+    // loop-invariant fragment addresses (slot 0): rows are 64 B, the swizzle ((R >> 2) & 3) depends on frow alone; ring slot and
+    // 32-row block go into the ds_read's immediate offset where they fit its 16 bits (the step loop is unrolled PIPE-fold so the slot is a constant)
+    const char* pafb[2];
+    const char* pwfb[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int sw = ((u * 2 + fhalf) ^ ((frow >> 2) & 3)) << 4;
+      pafb[u] = opaque(smem + (wm * WTM + frow) * 64 + sw);
+      pwfb[u] = opaque(smem + BM * 64 + (wn * WTN + frow) * 64 + sw);
+    }
+    auto pstep = [&](int st, auto rs) STAR_ALWAYS_INLINE {
+      constexpr int RS = decltype(rs)::value;             // ring slot read in this step
+      constexpr int IS = (RS + PIPE - 1) % PIPE;          // slot to be filled: read in step st-1, every wave is past its barrier
+      if (st + PIPE - 1 < nsteps) issue(st + PIPE - 1, IS);
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         vec<T, 8> af[TM], wf[TN];
-        const int c = u * 2 + fhalf;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          const int R = wm * WTM + i * 32 + frow;
-          af[i] = *reinterpret_cast<const vec<T, 8>*>(abuf + R * 64 + ((c ^ ((R >> 2) & 3)) << 4));
-        }
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const vec<T, 8>*>(pafb[u] + RS * SLOT + i * 2048);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int R = wn * WTN + j * 32 + frow;
-          wf[j] = *reinterpret_cast<const vec<T, 8>*>(wbuf + R * 64 + ((c ^ ((R >> 2) & 3)) << 4));
-        }
+        for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const vec<T, 8>*>(pwfb[u] + RS * SLOT + j * 2048);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -352,8 +363,19 @@ gemm_kernel(const GemmParams p) {
       const int remaining = nsteps - 1 - st;         // steps after this one
       wait_steps(remaining - 1 < INF ? remaining - 1 : INF);
       barrier_keep_dma();
-      rslot = (rslot + 1 == PIPE) ? 0 : rslot + 1;
-      islot = (islot + 1 == PIPE) ? 0 : islot + 1;
+    };
+    {
+      int st = 0;
+      for (; st + PIPE <= nsteps; st += PIPE) {          // PIPE steps per trip: the ring slot is a compile-time constant in each
+        pstep(st, std::integral_constant<int, 0>{});
+        if constexpr (PIPE > 1) pstep(st + 1, std::integral_constant<int, 1 % PIPE>{});
+        if constexpr (PIPE > 2) pstep(st + 2, std::integral_constant<int, 2 % PIPE>{});
+        if constexpr (PIPE > 3) pstep(st + 3, std::integral_constant<int, 3 % PIPE>{});
+      }
+      static_assert(PIPE <= 4, "the step loop is unrolled for rings of up to four slots");
+      if (st < nsteps) { pstep(st, std::integral_constant<int, 0>{}); ++st; }
+      if constexpr (PIPE > 2) { if (st < nsteps) { pstep(st, std::integral_constant<int, 1 % PIPE>{}); ++st; } }
+      if constexpr (PIPE > 3) { if (st < nsteps) { pstep(st, std::integral_constant<int, 2 % PIPE>{}); ++st; } }
     }
   } else {
   // Staggered wave groups.  The two waves that share a SIMD (w and w+4) belong to this same workgroup and meet at the

@@ -37,7 +37,7 @@ def dev(ctx, t):
     return t.to(ctx.torch_device)
 
 
-PRODUCT_TILES = (0, 1, 2, 3, 4, 9)
+PRODUCT_TILES = (0, 1, 2, 3, 4, 9, 10)
 
 
 _BENCH_CTX = {}
