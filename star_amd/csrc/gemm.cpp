@@ -173,10 +173,13 @@ int op_gemm(Ctx* ctx, const GemmArgs& a) {
   }
   if (a.M <= 0 || a.N <= 0) return 0;
   // the gathered modes address their input with 32-bit offsets from a per-tile base (gemm.h): keep them below 2^31
-  if (a.mode == A_CONV3X3 && (256 / ((long long)a.Ho * a.Wo) + 2) * a.H * a.Wd * a.lda * 2 >= (1LL << 31))
-    return ctx->fail("gemm: conv input frame too large for 32-bit gather offsets");
-  if (a.mode == A_TCONV3 && (2LL * a.HW + 256) * a.lda * 2 + 2LL * a.Cin >= (1LL << 31))
-    return ctx->fail("gemm: temporal-conv frame too large for 32-bit gather offsets");
+  if (a.mode == A_CONV3X3) {   // input rows one 256-row output tile can reach from its first source row
+    const long long hw = (long long)a.Ho * a.Wo;
+    const long long rows = hw > 256 ? 2 * ((256 / a.Wo + 3LL) * a.stride + 3) : (256 / hw + 2) * (a.H + 3LL);
+    if (rows * a.Wd * a.lda * 2 >= (1LL << 31)) return ctx->fail("gemm: conv image rows too large for 32-bit gather offsets");
+  }
+  if (a.mode == A_TCONV3 && (256LL * a.lda + a.Cin) * 2 >= (1LL << 31))
+    return ctx->fail("gemm: temporal-conv rows too large for 32-bit gather offsets");
   ProfScope ps(ctx, a.mode == A_PLAIN ? PK_GEMM : (a.mode == A_TCONV3 ? PK_TCONV : PK_CONV), 2.0 * a.M * (double)a.N * a.K,
                ((double)a.M * (a.mode == A_PLAIN ? a.K : a.Cin) + (double)a.M * ((a.epi & EPI_GEGLU) ? a.N / 2 : a.N)) * 2.0,
                a.M, a.N, a.K, a.epi);

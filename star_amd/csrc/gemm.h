@@ -129,16 +129,25 @@ gemm_kernel(const GemmParams p) {
   // non-negative multiples of a frame) -- a loop-invariant signed lane offset g_off to the lane's tap-0 source, a 9- / 3-bit
   // validity mask g_mask (bit = tap) and a uniform per-K-tile tap offset: two VALU adds/selects and one bit test per copy,
   // a padding tap is an out-of-range offset that the hardware turns into zeros (prim.h: glds16_buf).  The launcher checks
-  // that the offsets stay below 2^31.  The nearest-x2 conv (A_CONV3X3_UP: 3 layers per net) keeps per-lane 64-bit addresses.
+  // that the offsets (a few image rows / one row tile) stay below 2^31.  The nearest-x2 conv (A_CONV3X3_UP: 3 layers per net) keeps per-lane 64-bit addresses.
   const T* a_ptr[NA];             // A_CONV3X3_UP: frame base pointer (+ chunk offset)
   int a_y[NA], a_x[NA];           // A_CONV3X3_UP: upsampled-image coordinates of tap (0, 0)
   int g_off[NA];
   uint32_t g_mask[NA];
+  // 3x3 conv: the base is the first input row the tile's first pixel reads (frame g_nb0, row g_y0): every valid source of the
+  // tile lies at or behind it, within a few image rows (2160p VAE frames are > 2 GB: a frame-relative offset would not fit).
+  // Temporal conv: the base moves with the tap (one frame = up to 4 GB at 2160p), the lane offset is tile-relative.
   const char* g_base = (const char*)Ag;
   if constexpr (AMODE == A_TCONV3) g_base = (const char*)(Ag + ((ptrdiff_t)m0 - p.HW) * p.lda);
-  const int g_nb0 = (AMODE == A_CONV3X3) ? m0 / (p.Ho * p.Wo) : 0;
-  if constexpr (AMODE == A_CONV3X3) g_base = (const char*)(Ag + (size_t)g_nb0 * p.H * p.Wd * p.lda);
-  const BufRsrc g_rsrc = make_rsrc(g_base, GLDS_BUF_RANGE);
+  int g_nb0 = 0, g_y0 = 0;
+  if constexpr (AMODE == A_CONV3X3) {
+    const int hw = p.Ho * p.Wo;
+    g_nb0 = m0 / hw;
+    g_y0 = ((m0 - g_nb0 * hw) / p.Wo) * p.stride - p.pad_t;
+    if (g_y0 < 0) g_y0 = 0;
+    g_base = (const char*)(Ag + ((size_t)g_nb0 * p.H + g_y0) * p.Wd * p.lda);
+  }
+  BufRsrc g_rsrc = make_rsrc(g_base, GLDS_BUF_RANGE);
 #pragma unroll
   for (int j = 0; j < NA; ++j) {
     const int r = (j * NT + tid) >> 3;
@@ -159,7 +168,7 @@ gemm_kernel(const GemmParams p) {
       a_y[j] = yo * p.stride - p.pad_t;
       a_x[j] = xo * p.stride - p.pad_l;
       if constexpr (AMODE == A_CONV3X3) {
-        g_off[j] = ((((nb - g_nb0) * p.H + a_y[j]) * p.Wd + a_x[j]) * p.lda + c * 8) * 2;
+        g_off[j] = ((((nb - g_nb0) * p.H + a_y[j] - g_y0) * p.Wd + a_x[j]) * p.lda + c * 8) * 2;
 #pragma unroll
         for (int t9 = 0; t9 < 9; ++t9) {
           const int yi = a_y[j] + t9 / 3, xi = a_x[j] + t9 % 3;
@@ -189,7 +198,7 @@ gemm_kernel(const GemmParams p) {
     if constexpr (AMODE == A_CONV3X3 || AMODE == A_CONV3X3_UP) { ky = tap / 3; kx = tap - ky * 3; }
     // uniform byte offset of this K tile's (tap, channel block) from a lane's tap-0 source
     int tap_off = 0;
-    if constexpr (AMODE == A_TCONV3) tap_off = (tap * p.HW * p.lda + c0) * 2;
+    if constexpr (AMODE == A_TCONV3) { tap_off = c0 * 2; g_rsrc = make_rsrc(g_base + (size_t)tap * p.HW * p.lda * 2, GLDS_BUF_RANGE); }
     if constexpr (AMODE == A_CONV3X3) tap_off = ((ky * p.Wd + kx) * p.lda + c0) * 2;
     const uint32_t tap_bit = 1u << tap;
 #pragma unroll
