@@ -28,7 +28,7 @@ static int launch_flash(Ctx* ctx, const AttnArgs& a) {
     if (!once) {
       once = true;
       int nb = -1;
-      hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, flash_attn_v5_kernel<T, 0>, 256, 32768);
+      hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, flash_attn_v5_kernel<T, 0, 1>, 256, 32768);
       fprintf(stderr, "[star] flash_attn_v5<0>: %d workgroups of 256 threads per CU (err %d)\n", nb, (int)e);
     }
   }
@@ -36,12 +36,16 @@ static int launch_flash(Ctx* ctx, const AttnArgs& a) {
   if (a.variant == 9) {   // the shipped kernel (attn5.h).  Packed 16-bit row sums only where hundreds of key tiles average their
                           // rounding out (spatial self-attention); the 77-token cross-attention keeps fp32 row sums
     if constexpr (__is_same(T, f16)) {
-      if (a.Nk >= 1024) { STAR_LAUNCH((flash_attn_v5_kernel<T, 1>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p); return 0; }
+      if (a.Nk >= 1024) { STAR_LAUNCH((flash_attn_v5_kernel<T, 1, 1>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p); return 0; }
     }
-    STAR_LAUNCH((flash_attn_v5_kernel<T, 0>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);
+    STAR_LAUNCH((flash_attn_v5_kernel<T, 0, 1>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);
     return 0;
   }
 #ifdef STAR_BENCH_VARIANTS
+  if (a.variant == 33) {   // v5 with the augmented k-step as a full-depth 32x32x16 MFMA (the shipped kernel uses the half-depth 32x32x8 form)
+    if constexpr (__is_same(T, f16)) { STAR_LAUNCH((flash_attn_v5_kernel<T, 1, 0>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p); return 0; }
+    else { STAR_LAUNCH((flash_attn_v5_kernel<T, 0, 0>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p); return 0; }
+  }
   if (a.variant == 32) { STAR_LAUNCH((flash_attn_v3_kernel<T, 2, 1, 0, 1>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p); return 0; }   // the product kernel of rounds 1-2
   if (a.variant == 30) { STAR_LAUNCH((flash_attn_v5_kernel<T, 0>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p); return 0; }
   if (a.variant == 31) {

@@ -127,6 +127,35 @@ STAR_DEV f32x16 mfma32(vec<T, 8> a, vec<T, 8> b, f32x16 c) {
 #endif
 }
 
+// D = A(32x8) * B(8x32) + C (the pre-CDNA4 half-depth form).  lane l: a[j] = A[l&31][4*(l>>5)+j], b[j] = B[4*(l>>5)+j][l&31]
+template <class T>
+STAR_DEV f32x16 mfma32_k8(vec<T, 4> a, vec<T, 4> b, f32x16 c) {
+#ifdef STAR_HOSTEMU
+  struct P { float a[4], b[4]; } mine;
+  for (int j = 0; j < 4; ++j) { mine.a[j] = to_f32<T>(a[j]); mine.b[j] = to_f32<T>(b[j]); }
+  auto st = ::star_emu::wave_exchange(&mine, sizeof(mine));
+  const int l = lane_id();
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31;
+    float s = c[r];
+    for (int k = 0; k < 8; ++k) {
+      const P* pa = reinterpret_cast<const P*>(st[row + 32 * (k >> 2)]);
+      const P* pb = reinterpret_cast<const P*>(st[col + 32 * (k >> 2)]);
+      s += pa->a[k & 3] * pb->b[k & 3];
+    }
+    c[r] = s;
+  }
+  return c;
+#else
+  if constexpr (__is_same(T, bf16)) {
+    typedef short s4 __attribute__((ext_vector_type(4)));
+    return __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(__builtin_bit_cast(s4, a), __builtin_bit_cast(s4, b), c, 0, 0, 0);
+  } else {
+    return __builtin_amdgcn_mfma_f32_32x32x8f16(a, b, c, 0, 0, 0);
+  }
+#endif
+}
+
 // D = A(16x32) * B(32x16) + C. lane l: a[j] = A[l&15][8*(l>>4)+j], b[j] = B[8*(l>>4)+j][l&15], c[r] = C[4*(l>>4)+r][l&15]
 template <class T>
 STAR_DEV f32x4 mfma16(vec<T, 8> a, vec<T, 8> b, f32x4 c) {

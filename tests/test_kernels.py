@@ -261,7 +261,7 @@ def ref_attention(q, k, v, heads):
     return o.transpose(1, 2).reshape(B, -1, heads * 64)
 
 
-@pytest.mark.parametrize("variant", [2, 4, 5, 6, 7, 8, 9, 10, 20, 21, 22, 23, 27, 30, 31, 32])
+@pytest.mark.parametrize("variant", [2, 4, 5, 6, 7, 8, 9, 10, 20, 21, 22, 23, 27, 30, 31, 32, 33])
 @pytest.mark.parametrize("B,heads,Nq,Nk", [(2, 2, 300, 300), (1, 5, 80, 80), (3, 1, 257, 64), (1, 2, 64, 1), (9, 1, 33, 130), (1, 1, 130, 129)])
 def test_flash_attention_self(ctx, dtype, B, heads, Nq, Nk, variant):
     """spatial self-attention (unet_v2v.py:472 -> :184) on a fused QKV buffer, ragged q/k tails."""
@@ -305,7 +305,7 @@ def test_product_library_rejects_bench_variants(ctx, dtype):
     ctx.attention(q[..., :64], q[..., 64:128], q[..., 128:], 1, variant=0)   # 0 = default = the product kernel
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 15, 20, 21, 22, 23, 24, 27, 30, 31, 32])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 15, 20, 21, 22, 23, 24, 27, 30, 31, 32, 33])
 def test_flash_attention_variants_agree(ctx, dtype, variant):
     """all kernel variants (baseline / v2 / v3 with the augmented-k running max) against the fp32 reference, incl. a
     ragged key tail, strongly negative logits in tile 0 and a late spike that forces the rescale branch."""
@@ -324,7 +324,7 @@ def test_flash_attention_variants_agree(ctx, dtype, variant):
     assert_close(out, ref_attention(q, k, v, heads), dtype, scale=6.0, what=f"flash variant {variant}")
 
 
-@pytest.mark.parametrize("variant", [2, 6, 7, 8, 9, 10, 15, 20, 21, 22, 27, 30, 31, 32])
+@pytest.mark.parametrize("variant", [2, 6, 7, 8, 9, 10, 15, 20, 21, 22, 27, 30, 31, 32, 33])
 def test_flash_attention_forced_rescale(ctx, dtype, variant):
     """a key spike late in the sequence forces the online-softmax rescale branch with a large max jump."""
     ctx = need_variant(ctx, variant == 9)
@@ -342,7 +342,7 @@ def test_flash_attention_forced_rescale(ctx, dtype, variant):
     assert_close(out, ref_attention(q, k, v, heads), dtype, what="flash rescale")
 
 
-@pytest.mark.parametrize("variant", [2, 6, 7, 8, 9, 10, 15, 20, 21, 22, 27, 30, 31, 32])
+@pytest.mark.parametrize("variant", [2, 6, 7, 8, 9, 10, 15, 20, 21, 22, 27, 30, 31, 32, 33])
 def test_flash_attention_growing_max(ctx, dtype, variant):
     """scores that keep growing along the key axis (every tile moves the maximum by several binades, some by more than
     the fp16 exponent range) and a first tile far below everything that follows: the lazy-max variants must take their
