@@ -14,24 +14,31 @@ static int launch_gemm_f(Ctx* ctx, const GemmArgs& a) {
   p.M = a.M; p.N = a.N; p.K = a.K; p.lda = a.lda; p.ldc = a.ldc; p.ldr = a.ldr;
   p.H = a.H; p.Wd = a.Wd; p.Cin = a.Cin; p.Ho = a.Ho; p.Wo = a.Wo; p.stride = a.stride; p.pad_t = a.pad_t; p.pad_l = a.pad_l;
   p.HW = a.HW; p.F = a.F; p.up_crop = a.up_crop; p.epi = a.epi;
+  p.rowab = a.rowab; p.colsum = a.colsum;
   p.tiles_m = (a.M + BM - 1) / BM;
   p.tiles_n = (a.N + BN - 1) / BN;
   // 2 stages x 64 k, or PIPE ring slots x 32 k; never less than the epilogue's per-wave staging blocks
   constexpr size_t smem_loop = PIPE ? (size_t)PIPE * (BM + BN) * 64 : 2 * (size_t)(BM + BN) * 128;
   constexpr size_t smem_epi = (size_t)WM * WN * 32 * (BN / WN * 2 + 8);
   static_assert(smem_epi <= smem_loop, "the epilogue's staging blocks must fit under the bias slice");
-  constexpr size_t smem = smem_loop + (size_t)BN * sizeof(float);   // + this tile's bias slice
+  constexpr size_t smem = smem_loop + 2 * (size_t)BN * sizeof(float);   // + this tile's bias slice (+ column sums of a folded LayerNorm)
   unsigned nwg = (unsigned)(p.tiles_m * p.tiles_n);
   if (a.persist > 0 && nwg > (unsigned)a.persist) nwg = (unsigned)a.persist;   // persistent tile walk (gemm.h)
   dim3 grid(nwg), block(WM * WN * 64);
   // 16-bit epilogue flavour (compile-time in the kernel): plain / + residual / GEGLU (plain-A layers only, no residual)
   const bool res = !F32OUT && (a.epi & EPI_RES), geglu = !F32OUT && (a.epi & EPI_GEGLU), gelut = !F32OUT && (a.epi & EPI_GELU_TANH);
   if ((geglu || gelut) && (res || a.mode != A_PLAIN || (geglu && gelut))) return ctx->fail("gemm: GEGLU / tanh-GELU are for plain-A layers without a residual");
+  const bool rowaff = !F32OUT && (a.epi & EPI_ROWAFF);
+  if (rowaff && (res || gelut || a.mode != A_PLAIN || !a.rowab || !a.colsum || !(a.epi & EPI_BIAS)))
+    return ctx->fail("gemm: the folded-LayerNorm epilogue is for plain-A layers without a residual and needs rowab, colsum and bias");
 #define STAR_GEMM_GO(MODE, EF) STAR_LAUNCH((gemm_kernel<T, BM, BN, WM, WN, MODE, MINW, F32OUT, STAGGER, 0, PIPE, EF>), grid, block, smem, ctx->stream, p)
   switch (a.mode) {
     case A_PLAIN:
       if constexpr (F32OUT) STAR_GEMM_GO(A_PLAIN, 0);
-      else { if (geglu) STAR_GEMM_GO(A_PLAIN, 2); else if (gelut) STAR_GEMM_GO(A_PLAIN, 4); else if (res) STAR_GEMM_GO(A_PLAIN, 1); else STAR_GEMM_GO(A_PLAIN, 0); }
+      else {
+        if (rowaff) { if (geglu) STAR_GEMM_GO(A_PLAIN, 10); else STAR_GEMM_GO(A_PLAIN, 8); }
+        else if (geglu) STAR_GEMM_GO(A_PLAIN, 2); else if (gelut) STAR_GEMM_GO(A_PLAIN, 4); else if (res) STAR_GEMM_GO(A_PLAIN, 1); else STAR_GEMM_GO(A_PLAIN, 0);
+      }
       break;
     case A_CONV3X3:
       if constexpr (F32OUT) STAR_GEMM_GO(A_CONV3X3, 0); else { if (res) STAR_GEMM_GO(A_CONV3X3, 1); else STAR_GEMM_GO(A_CONV3X3, 0); }

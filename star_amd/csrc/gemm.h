@@ -40,6 +40,10 @@ struct GemmParams {
   int up_crop;   // A_CONV3X3_UP: rows dropped at top and bottom of the 2x-upsampled image (1: UNet Upsample, 0: VAE Upsample2D)
   int epi;
   int tiles_m, tiles_n;
+  // EPI_ROWAFF (LayerNorm folded into this GEMM): out = a_m * acc + b_m * s_n + c_n with (a_m, b_m) = rowab[m], s_n = colsum[n],
+  // c_n = bias[n]
+  const float* rowab;   // [M][2]
+  const float* colsum;  // [N]
 };
 
 // exact (erf) GELU, F.gelu default (unet_v2v.py:504): gelu(x) = max(x, 0) - |x| q(|x|), q(t) = 0.5 erfc(t / sqrt 2).
@@ -69,7 +73,7 @@ STAR_DEV float gelu_tanh(float x) {
   return x * fast_rcp(1.0f + fast_exp2(-2.8853900817779268f * u));
 }
 
-template <class T, int BM, int BN, int WM, int WN, int AMODE, int MINW, bool F32OUT, bool STAGGER, int ABL = 0, int PIPE = 0, int EPIF = 0>  // ABL: ablation probes (bench only); PIPE: ring slots of the pipelined loop (0 = 2-stage loop); EPIF: 16-bit epilogue flavour (bit 0 residual add, bit 1 GEGLU, bit 2 tanh-GELU)
+template <class T, int BM, int BN, int WM, int WN, int AMODE, int MINW, bool F32OUT, bool STAGGER, int ABL = 0, int PIPE = 0, int EPIF = 0>  // ABL: ablation probes (bench only); PIPE: ring slots of the pipelined loop (0 = 2-stage loop); EPIF: 16-bit epilogue flavour (bit 0 residual add, bit 1 GEGLU, bit 2 tanh-GELU, bit 3 row-affine = folded LayerNorm)
 STAR_GLOBAL void STAR_LAUNCH_BOUNDS(WM * WN * 64, MINW)
 gemm_kernel(const GemmParams p) {
   constexpr int NT = WM * WN * 64;
@@ -81,7 +85,7 @@ gemm_kernel(const GemmParams p) {
   static_assert(NT % 8 == 0, "");
   constexpr int A_STAGE = BM * 128, W_STAGE = BN * 128;
   constexpr int STAGE = A_STAGE + W_STAGE;
-  constexpr int SMEM_LOOP = PIPE ? PIPE * (BM + BN) * 64 : 2 * STAGE;   // bytes of the main loop's buffers; bias[BN] fp32 follows
+  constexpr int SMEM_LOOP = PIPE ? PIPE * (BM + BN) * 64 : 2 * STAGE;   // bytes of the main loop's buffers; bias[BN] (+ colsum[BN]) fp32 follow
 
   char* smem = dyn_smem();
 
@@ -109,6 +113,9 @@ gemm_kernel(const GemmParams p) {
   if constexpr (!F32OUT) {   // this tile's bias slice, read from LDS in the epilogue (visible after the main loop's barriers)
     float* bl = reinterpret_cast<float*>(smem + SMEM_LOOP);
     for (int n = tid; n < BN; n += NT) bl[n] = ((p.epi & EPI_BIAS) && n0 + n < p.N) ? p.bias[n0 + n] : 0.f;
+    if constexpr ((EPIF & 8) != 0) {
+      for (int n = tid; n < BN; n += NT) bl[BN + n] = (n0 + n < p.N) ? p.colsum[n0 + n] : 0.f;
+    }
   }
 
   const T* __restrict__ Ag = (const T*)p.A;
@@ -499,7 +506,7 @@ gemm_kernel(const GemmParams p) {
     // Residual / GEGLU are compile-time (EPIF: bit 0 residual, bit 1 GEGLU): every index below folds to constants, the
     // residual registers exist only where a residual is added, and the residual loads are unconditional (rows and columns
     // clamped into the matrix instead of exec-masked), so nothing of the epilogue stays live across the K loop.
-    constexpr bool RESF = (EPIF & 1) != 0, GEGLUF = (EPIF & 2) != 0, GELUTF = (EPIF & 4) != 0;
+    constexpr bool RESF = (EPIF & 1) != 0, GEGLUF = (EPIF & 2) != 0, GELUTF = (EPIF & 4) != 0, ROWAFF = (EPIF & 8) != 0;
     constexpr int out_wtn = GEGLUF ? WTN / 2 : WTN;   // output columns per wave
     const int out_n0 = GEGLUF ? (n0 + wn * WTN) / 2 : (n0 + wn * WTN);
     const int N_out = GEGLUF ? p.N / 2 : p.N;
@@ -545,6 +552,17 @@ gemm_kernel(const GemmParams p) {
       }
     };
 
+    // folded LayerNorm: this lane's rows (the swapped MFMA gives a lane one row per 32-row block) and their (a, b)
+    float ra[TM], rb[TM];
+    if constexpr (ROWAFF) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        int m = m0 + wm * WTM + i * 32 + frow;
+        if (m > p.M - 1) m = p.M - 1;
+        const vec<float, 2> ab = *reinterpret_cast<const vec<float, 2>*>(p.rowab + 2 * (size_t)m);
+        ra[i] = ab[0]; rb[i] = ab[1];
+      }
+    }
     load_res(0);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -558,12 +576,22 @@ gemm_kernel(const GemmParams p) {
           f32x4 v;
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = acc[i][j][g * 4 + e];
+          if constexpr (ROWAFF) {
+            const f32x4 cs = *reinterpret_cast<const f32x4*>(bias_lds + BN + nl), cb = *reinterpret_cast<const f32x4*>(bias_lds + nl);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = ra[i] * v[e] + (rb[i] * cs[e] + cb[e]);
+          } else
           v += *reinterpret_cast<const f32x4*>(bias_lds + nl);   // zeros when the layer has no bias
           int ncol = nl;
           if constexpr (GEGLUF) {
             f32x4 gt;
 #pragma unroll
             for (int e = 0; e < 4; ++e) gt[e] = acc[i][(j + 1 < TN) ? j + 1 : j][g * 4 + e];
+            if constexpr (ROWAFF) {
+              const f32x4 cs = *reinterpret_cast<const f32x4*>(bias_lds + BN + nl + 32), cb = *reinterpret_cast<const f32x4*>(bias_lds + nl + 32);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) gt[e] = ra[i] * gt[e] + (rb[i] * cs[e] + cb[e]);
+            } else
             gt += *reinterpret_cast<const f32x4*>(bias_lds + nl + 32);
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = v[e] * gelu_erf(gt[e]);

@@ -15,7 +15,7 @@ struct DevW {            // a device-resident parameter tensor
   void* p = nullptr;
   int64_t n = 0;
 };
-struct LinW { DevW w; DevW b; int N = 0, K = 0; };   // w: T [N][K]; b: fp32 [N] (may be empty)
+struct LinW { DevW w; DevW b; int N = 0, K = 0; DevW colsum; };   // w: T [N][K]; b: fp32 [N] (may be empty); colsum: fp32 [N], folded-LayerNorm layers only
 struct NormW { DevW g, b; int C = 0; };               // fp32
 
 struct Builder {
@@ -150,6 +150,67 @@ struct Builder {
     l.N = N2; l.K = K; l.w = upload_T(r); l.b = upload_f32(rb);
     return l;
   }
+  static float round16(float v, int dtype) {
+    const uint16_t u = cvt16(v, dtype);
+    if (dtype == DT_F16) { f16 h; memcpy(&h, &u, 2); return (float)h; }
+    const uint32_t w = (uint32_t)u << 16; float f; memcpy(&f, &w, 4); return f;
+  }
+  // A LayerNorm folded into the Linear(s) it feeds (the only consumers of its output): y = LN(x) W^T + b with
+  // LN(x) = (a_m x + b_m) gamma + beta per row  =>  y[m][n] = a_m (x W'^T)[m][n] + b_m s_n + c_n,  W' = gamma o W (stored in T),
+  // s_n = sum_k W'[n][k] (of the ROUNDED weights, so the mean term cancels exactly what the MFMA accumulated),
+  // c_n = sum_k beta_k W[n][k] + b_n.  `rows` = the weight matrices stacked along N (fused q|k|v), already in kernel row order.
+  LinW fold_ln(const std::vector<float>& w, const std::vector<float>& bias, int N, int K, const std::string& norm) {
+    LinW l;
+    const HostTensor* g = get(norm + ".weight"); const HostTensor* be = get(norm + ".bias");
+    if (!g || !be) return l;
+    if ((int)g->data.size() != K) { if (err.empty()) err = "fold_ln: LayerNorm width does not match " + norm; return l; }
+    std::vector<float> wf((size_t)N * K), cs(N), cb(N);
+    for (int n = 0; n < N; ++n) {
+      double s = 0.0, c = 0.0;
+      for (int k = 0; k < K; ++k) {
+        const float v = w[(size_t)n * K + k] * g->data[k];
+        wf[(size_t)n * K + k] = v;
+        s += (double)round16(v, ctx->dtype);
+        c += (double)be->data[k] * (double)w[(size_t)n * K + k];
+      }
+      cs[n] = (float)s;
+      cb[n] = (float)c + (bias.empty() ? 0.f : bias[n]);
+    }
+    l.N = N; l.K = K; l.w = upload_T(wf); l.b = upload_f32(cb); l.colsum = upload_f32(cs);
+    return l;
+  }
+  LinW linear_ln(const std::string& p, const std::string& norm, bool has_bias = true) {
+    const HostTensor* w = get(p + ".weight");
+    if (!w) return LinW{};
+    const int N = (int)w->shape[0], K = (int)(w->data.size() / (size_t)N);
+    std::vector<float> b;
+    if (has_bias) { const HostTensor* bb = get(p + ".bias"); if (!bb) return LinW{}; b = bb->data; }
+    return fold_ln(w->data, b, N, K, norm);
+  }
+  LinW fused_ln(const std::vector<std::string>& names, const std::string& norm) {
+    std::vector<float> r; int N = 0, K = 0;
+    for (auto& nm : names) {
+      const HostTensor* w = get(nm + ".weight");
+      if (!w) return LinW{};
+      K = (int)(w->data.size() / (size_t)w->shape[0]); N += (int)w->shape[0];
+      r.insert(r.end(), w->data.begin(), w->data.end());
+    }
+    return fold_ln(r, {}, N, K, norm);
+  }
+  LinW geglu_ln(const std::string& p, const std::string& norm) {
+    const HostTensor* w = get(p + ".weight"); const HostTensor* b = get(p + ".bias");
+    if (!w || !b) return LinW{};
+    const int N2 = (int)w->shape[0], K = (int)w->shape[1], Hh = N2 / 2;
+    std::vector<float> r((size_t)N2 * K), rb(N2);
+    for (int blk = 0; blk < Hh / 32; ++blk)
+      for (int half = 0; half < 2; ++half)
+        for (int i = 0; i < 32; ++i) {
+          const int src = half * Hh + blk * 32 + i, dst = blk * 64 + half * 32 + i;
+          memcpy(&r[(size_t)dst * K], &w->data[(size_t)src * K], (size_t)K * 4);
+          rb[dst] = b->data[src];
+        }
+    return fold_ln(r, rb, N2, K, norm);
+  }
   DevW raw_f32(const std::string& name) {
     const HostTensor* t = get(name);
     return t ? upload_f32(t->data) : DevW{};
@@ -210,6 +271,18 @@ struct Runner {
   }
   void ln(const void* x, void* y, int rws, int C, const NormW& n, int mode = LN_PLAIN, const float* gw = nullptr, float* maps = nullptr, int H = 0, int W = 0) {
     ok(op_layer_norm(ctx, x, C, y, C, (const float*)n.g.p, (const float*)n.b.p, rws, C, 1e-5f, mode, gw, maps, H, W));
+  }
+  // the row statistics of a LayerNorm that is folded into the next GEMM: rowab[m] = (a_m, b_m); x is read once, nothing is written back
+  void ln_rows(const void* x, float* rowab, int rws, int C, int mode = LN_PLAIN, const float* gw = nullptr, float* maps = nullptr, int H = 0, int W = 0) {
+    ok(op_layer_norm(ctx, x, C, nullptr, C, nullptr, nullptr, rws, C, 1e-5f, mode, gw, maps, H, W, rowab));
+  }
+  // y = LN(x) W^T + b through the folded form (w built by Builder::*_ln)
+  void gemm_ln(const void* A, int lda, int M, const LinW& w, const float* rowab, void* C, int ldc, int extra_epi = 0) {
+    GemmArgs g;
+    g.A = A; g.W = w.w.p; g.C = C; g.M = M; g.N = w.N; g.K = w.K; g.lda = lda; g.ldc = ldc;
+    g.bias = (const float*)w.b.p; g.rowab = rowab; g.colsum = (const float*)w.colsum.p;
+    g.epi = EPI_BIAS | EPI_ROWAFF | extra_epi;
+    ok(op_gemm(ctx, g));
   }
 
 };

@@ -60,12 +60,12 @@ static int ln_t(Ctx* ctx, LnParams p) {
 }
 
 int op_layer_norm(Ctx* ctx, const void* x, int ldx, void* y, int ldy, const float* gamma, const float* beta,
-                  int rows, int C, float eps, int mode, const float* gate_w, float* maps, int H, int W) {
+                  int rows, int C, float eps, int mode, const float* gate_w, float* maps, int H, int W, float* rowab) {
   if (C % 8) return ctx->fail("layer_norm: C must be a multiple of 8");
   if ((ldx | ldy) & 7) return ctx->fail("layer_norm: row strides must be multiples of 8");
   if (rows <= 0) return 0;
-  ProfScope ps(ctx, PK_LN, 0.0, (mode == LN_STATS_ONLY ? 1.0 : 2.0) * rows * (double)C * 2.0);
-  LnParams p{x, y, gamma, beta, gate_w, maps, ldx, ldy, C, rows, H, W, eps, mode, 64};
+  ProfScope ps(ctx, PK_LN, 0.0, ((mode == LN_STATS_ONLY || rowab) ? 1.0 : 2.0) * rows * (double)C * 2.0);
+  LnParams p{x, y, gamma, beta, gate_w, maps, ldx, ldy, C, rows, H, W, eps, mode, 64, rowab};
   if (ctx->dtype == DT_F16) return ln_t<f16>(ctx, p);
   return ln_t<bf16>(ctx, p);
 }

@@ -165,6 +165,8 @@ struct LnParams {
   float* maps;           // [tokens][2] (written by STATS_ONLY, read by GATE_MAP)
   int ldx, ldy, C, rows; int H, W;  // H,W: image size for GATE_MAP (token = (f*H + y)*W + x)
   float eps; int mode; int lpr;
+  float* rowab;          // non-null: do not write y; write rowab[token] = (a, b) with LN(gate x) = (a x + b) gamma + beta, for the
+                         // GEMM that has this LayerNorm folded into its weights and epilogue (gemm.h EPI_ROWAFF)
 };
 // A row is shared by LPR = 8 / 16 / 32 / 64 lanes (<= 5 16-B chunks per lane), so a wavefront normalises 64/LPR rows at
 // once and every lane is busy at every layer width (C = 320: 8 lanes x 5 chunks, 8 rows per wave; C = 2560: one row).
@@ -238,6 +240,10 @@ STAR_GLOBAL void ln_kernel(const LnParams p) {
   sq = group_sum(sq);
   const float rstd = 1.0f / sqrtf(sq * inv_c + p.eps);
   if (!active) return;
+  if (p.rowab) {     // (gate x - gate mean) rstd = a x + b
+    if (sub == 0) { p.rowab[2 * (size_t)row] = gate * rstd; p.rowab[2 * (size_t)row + 1] = -rstd * mean; }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < CPL; ++i) {
     const int cc = sub + LPR * i;

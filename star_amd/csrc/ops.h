@@ -29,6 +29,7 @@ struct GemmArgs {
   int up_crop = 1;
   int epi = 0;
   int force_tile = 0;  // 0 = auto; 1 = 256x256, 2 = 256x320, 3 = 128x128, 4 = 256x128 (tests)
+  const float* rowab = nullptr; const float* colsum = nullptr;   // EPI_ROWAFF operands
   int persist = 0;     // > 0: at most this many workgroups walk the output tiles (multiple of 8); 0 = one workgroup per tile
 };
 int op_gemm(Ctx* ctx, const GemmArgs& a);
@@ -60,7 +61,7 @@ int op_temporal_attn(Ctx* ctx, const TAttnArgs& a);
 int op_group_norm(Ctx* ctx, const void* x, int ldx, void* y, int ldy, const float* gamma, const float* beta,
                   int rows, int C, int rows_per_stat, float eps, bool silu);
 int op_layer_norm(Ctx* ctx, const void* x, int ldx, void* y, int ldy, const float* gamma, const float* beta,
-                  int rows, int C, float eps, int mode, const float* gate_w, float* maps, int H, int W);
+                  int rows, int C, float eps, int mode, const float* gate_w, float* maps, int H, int W, float* rowab = nullptr);
 int op_concat_add(Ctx* ctx, const void* a, const void* b, const void* c, void* out, int rows, int C1, int C2);
 int op_add(Ctx* ctx, const void* a, const void* b, void* out, long long n);
 int op_stem_im2col(Ctx* ctx, const float* latent, void* out, int Cl, int F, int H, int W, bool frame_major = false);

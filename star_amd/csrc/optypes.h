@@ -14,6 +14,7 @@ enum GemmEpi : int {
   EPI_RES = 2,     // + res[m][n] (T, row stride ldr)
   EPI_GEGLU = 4,   // weight rows interleaved in 32-row (value, gate) blocks: out[m][n/2] = (v+bv) * gelu_erf(g+bg)
   EPI_OUT_F32 = 8, // store fp32 instead of T
+  EPI_ROWAFF = 32, // LayerNorm folded into the GEMM: out = a_m * acc + b_m * colsum[n] + bias[n], (a_m, b_m) = rowab[m] (gemm.h)
   EPI_GELU_TANH = 16, // out = gelu_tanh(acc + bias): the DiT MLP's activation (sat's gelu_impl, cogvideox-based/transformer.py:202-313)
 };
 

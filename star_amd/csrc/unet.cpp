@@ -37,18 +37,19 @@ struct UBuilder : Builder {
   }
   TBlockW tblock(const std::string& p, bool spatial) {
     TBlockW t;
-    t.n1 = norm(p + ".norm1"); t.n2 = norm(p + ".norm2"); t.n3 = norm(p + ".norm3");
-    t.qkv1 = fused({p + ".attn1.to_q", p + ".attn1.to_k", p + ".attn1.to_v"});
+    // norm1 / norm2 / norm3 feed only the projections behind them: each LayerNorm is folded into its GEMM (graph.h: fold_ln);
+    // what is left of it at run time is one read of the row for (a_m, b_m)
+    t.qkv1 = fused_ln({p + ".attn1.to_q", p + ".attn1.to_k", p + ".attn1.to_v"}, p + ".norm1");
     t.out1 = linear(p + ".attn1.to_out.0");
     if (spatial) {
-      t.q2 = linear(p + ".attn2.to_q", false);
+      t.q2 = linear_ln(p + ".attn2.to_q", p + ".norm2", false);
       t.kv2 = fused({p + ".attn2.to_k", p + ".attn2.to_v"});
     } else {
-      t.qkv2 = fused({p + ".attn2.to_q", p + ".attn2.to_k", p + ".attn2.to_v"});
+      t.qkv2 = fused_ln({p + ".attn2.to_q", p + ".attn2.to_k", p + ".attn2.to_v"}, p + ".norm2");
       t.local2 = raw_f32(p + ".local2.conv1.weight");
     }
     t.out2 = linear(p + ".attn2.to_out.0");
-    t.ff1 = geglu(p + ".ff.net.0.proj");
+    t.ff1 = geglu_ln(p + ".ff.net.0.proj", p + ".norm3");
     t.ff2 = linear(p + ".ff.net.2");
     t.local1 = raw_f32(p + ".local1.conv1.weight");
     return t;
@@ -117,12 +118,12 @@ struct Fwd : Runner {
 
   // shared tail of both transformer kinds: LN3 -> GEGLU FF -> +res ; then proj_out (+ x_in)
   void ff_and_out(const TBlockW& tb, Act& h2, int R, int inner, const LinW& proj_out, const Act& x_in, Act& out) {
-    Act l3 = make(inner, x_in.H, x_in.W);
-    ln(h2.p(), l3.p(), R, inner, tb.n3);
+    Buf ab(ctx, (size_t)R * 2 * 4);
+    ln_rows(h2.p(), ab.as<float>(), R, inner);                         // norm3, folded into the GEGLU projection
     Buf g(ctx, (size_t)R * inner * 4 * es);
-    if (!g.p) { rc = ctx->fail("out of device memory (ff)"); return; }
-    gemm(l3.p(), inner, R, tb.ff1, g.p, inner * 4, nullptr, 0, EPI_GEGLU);
-    l3.drop();
+    if (!g.p || !ab.p) { rc = ctx->fail("out of device memory (ff)"); return; }
+    gemm_ln(h2.p(), inner, R, tb.ff1, ab.as<float>(), g.p, inner * 4, EPI_GEGLU);
+    ab.reset();
     Act h3 = make(inner, x_in.H, x_in.W);
     gemm(g.p, inner * 4, R, tb.ff2, h3.p(), inner, h2.p(), inner);
     g.reset(); h2.drop();
@@ -141,15 +142,16 @@ struct Fwd : Runner {
     gn(x, s.norm, n, false, 1e-6f, false);
     Act h = make(C, x.H, x.W);
     gemm(n.p(), C, R, s.proj_in, h.p(), C);
-    // LIEM spatial gate + LN1
-    Buf maps(ctx, (size_t)R * 2 * 4);
-    ln(h.p(), nullptr, R, C, tb.n1, LN_STATS_ONLY, nullptr, maps.as<float>());
-    ln(h.p(), n.p(), R, C, tb.n1, LN_GATE_MAP, (const float*)tb.local1.p, maps.as<float>(), x.H, x.W);
+    // LIEM spatial gate + LN1 (folded into the QKV projection: rows of h are read for their statistics only)
+    Buf maps(ctx, (size_t)R * 2 * 4), ab(ctx, (size_t)R * 2 * 4);
+    ln_rows(h.p(), nullptr, R, C, LN_STATS_ONLY, nullptr, maps.as<float>());
+    ln_rows(h.p(), ab.as<float>(), R, C, LN_GATE_MAP, (const float*)tb.local1.p, maps.as<float>(), x.H, x.W);
     maps.reset();
     // self attention over the H*W tokens of each frame
     Buf qkv(ctx, (size_t)R * 3 * C * es);
-    if (!qkv.p) { rc = ctx->fail("out of device memory (qkv)"); return mid; }
-    gemm(n.p(), C, R, tb.qkv1, qkv.p, 3 * C);
+    if (!qkv.p || !ab.p) { rc = ctx->fail("out of device memory (qkv)"); return mid; }
+    gemm_ln(h.p(), C, R, tb.qkv1, ab.as<float>(), qkv.p, 3 * C);
+    ab.reset();
     {
       AttnArgs a;
       a.Q = qkv.p; a.K = (char*)qkv.p + (size_t)C * es; a.V = (char*)qkv.p + (size_t)2 * C * es; a.O = n.p();
@@ -168,9 +170,12 @@ struct Fwd : Runner {
     const int R = rows(x), C = s.C, HW = x.H * x.W;
     const TBlockW& tb = s.tb;
     Act n = make(C, x.H, x.W);
-    ln(mid.h1.p(), n.p(), R, C, tb.n2);
+    Buf ab(ctx, (size_t)R * 2 * 4);
+    ln_rows(mid.h1.p(), ab.as<float>(), R, C);                          // norm2, folded into to_q
     Act q2 = make(C, x.H, x.W);
-    gemm(n.p(), C, R, tb.q2, q2.p(), C);
+    if (!ab.p) { rc = ctx->fail("out of device memory"); return n; }
+    gemm_ln(mid.h1.p(), C, R, tb.q2, ab.as<float>(), q2.p(), C);
+    ab.reset();
     Buf kv(ctx, (size_t)77 * 2 * C * es);
     gemm(context_T, ctx_dim, 77, tb.kv2, kv.p, 2 * C);
     {
@@ -204,12 +209,13 @@ struct Fwd : Runner {
     gemm(n.p(), C, R, s.proj_in, h.p(), I);
     n.drop();
     Act l = make(I, x.H, x.W);
-    Buf qkv(ctx, (size_t)R * 3 * I * es);
-    if (!qkv.p) { rc = ctx->fail("out of device memory (qkv)"); return x; }
+    Buf qkv(ctx, (size_t)R * 3 * I * es), ab(ctx, (size_t)R * 2 * 4);
+    if (!qkv.p || !ab.p) { rc = ctx->fail("out of device memory (qkv)"); return x; }
     Act cur = std::move(h);
     for (int pass = 0; pass < 2; ++pass) {
-      ln(cur.p(), l.p(), R, I, pass == 0 ? tb.n1 : tb.n2, LN_GATE_LINEAR, (const float*)(pass == 0 ? tb.local1.p : tb.local2.p));
-      gemm(l.p(), I, R, pass == 0 ? tb.qkv1 : tb.qkv2, qkv.p, 3 * I);
+      // temporal LIEM gate + LayerNorm, folded into the QKV projection
+      ln_rows(cur.p(), ab.as<float>(), R, I, LN_GATE_LINEAR, (const float*)(pass == 0 ? tb.local1.p : tb.local2.p));
+      gemm_ln(cur.p(), I, R, pass == 0 ? tb.qkv1 : tb.qkv2, ab.as<float>(), qkv.p, 3 * I);
       TAttnArgs a;
       a.Q = qkv.p; a.K = (char*)qkv.p + (size_t)I * es; a.V = (char*)qkv.p + (size_t)2 * I * es; a.O = l.p();
       a.ldq = a.ldk = a.ldv = 3 * I; a.ldo = I; a.F = F; a.HW = HW; a.heads = s.heads; a.scale = 0.125f;
@@ -218,7 +224,7 @@ struct Fwd : Runner {
       gemm(l.p(), I, R, pass == 0 ? tb.out1 : tb.out2, nx.p(), I, cur.p(), I);
       cur = std::move(nx);
     }
-    qkv.reset(); l.drop();
+    qkv.reset(); l.drop(); ab.reset();
     Act out = make(C, x.H, x.W);
     ff_and_out(tb, cur, R, I, s.proj_out, x, out);
     return out;
