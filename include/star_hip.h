@@ -28,7 +28,10 @@ enum { STAR_F16 = 0, STAR_BF16 = 1, STAR_F32 = 2 };
 /* A-operand gather modes of star_gemm (see star_amd/csrc/gemm.h) */
 enum { STAR_A_PLAIN = 0, STAR_A_CONV3X3 = 1, STAR_A_CONV3X3_UP = 2, STAR_A_TCONV3 = 3 };
 /* epilogue flags of star_gemm */
-enum { STAR_EPI_BIAS = 1, STAR_EPI_RES = 2, STAR_EPI_GEGLU = 4, STAR_EPI_OUT_F32 = 8 };
+enum { STAR_EPI_BIAS = 1, STAR_EPI_RES = 2, STAR_EPI_GEGLU = 4, STAR_EPI_OUT_F32 = 8,
+       STAR_EPI_GELU_TANH = 16   /* out = gelu_tanh(acc + bias): the DiT MLP activation (plain-A layers, no residual) */ };
+/* (bit 32, the folded-LayerNorm epilogue, is internal to star_unet_forward: it needs per-row and per-column operands the descriptor
+ * does not carry, and star_gemm rejects it) */
 
 /* ---- context ------------------------------------------------------------ */
 /* replaces: VideoToVideo_sr.__init__ device selection (video_to_video_model.py:21-34,42) */
