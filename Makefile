@@ -8,7 +8,7 @@ HIPCC ?= hipcc
 CLANGXX ?= /opt/rocm/lib/llvm/bin/clang++
 HIP_OBJS := $(patsubst $(CSRC)/%.cpp,build/hip/%.o,$(SRCS))
 EMU_OBJS := $(patsubst $(CSRC)/%.cpp,build/emu/%.o,$(SRCS)) build/emu/hostemu.o
-HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -x hip -Wno-unused-value -ffp-contract=fast
+HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -x hip -Wno-unused-value -Wno-inline-asm -ffp-contract=fast
 EMUFLAGS := -O2 -g -std=c++17 -fPIC -DSTAR_HOSTEMU=1 -DSTAR_BENCH_VARIANTS=1 -mavx2 -mf16c -mfma -Wno-unused-value -Wno-psabi -Wno-psabi
 
 all: hip emu
