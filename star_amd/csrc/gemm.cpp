@@ -7,7 +7,9 @@
 
 namespace star {
 
-template <class T, int BM, int BN, int WM, int WN, int MINW, bool F32OUT, bool STAGGER, int PIPE = 0>
+// ALLEPI: also instantiate the tanh-GELU and folded-LayerNorm epilogue flavours (the auto-selected tiles 1-4 only: every
+// flavour is one more kernel per tile, mode and dtype, and gemm.cpp is the longest compile of the build)
+template <class T, int BM, int BN, int WM, int WN, int MINW, bool F32OUT, bool STAGGER, int PIPE = 0, bool ALLEPI = false>
 static int launch_gemm_f(Ctx* ctx, const GemmArgs& a) {
   GemmParams p{};
   p.A = a.A; p.W = a.W; p.C = a.C; p.bias = a.bias; p.res = a.res; p.zero_page = ctx->zero_page;
@@ -36,8 +38,13 @@ static int launch_gemm_f(Ctx* ctx, const GemmArgs& a) {
     case A_PLAIN:
       if constexpr (F32OUT) STAR_GEMM_GO(A_PLAIN, 0);
       else {
-        if (rowaff) { if (geglu) STAR_GEMM_GO(A_PLAIN, 10); else STAR_GEMM_GO(A_PLAIN, 8); }
-        else if (geglu) STAR_GEMM_GO(A_PLAIN, 2); else if (gelut) STAR_GEMM_GO(A_PLAIN, 4); else if (res) STAR_GEMM_GO(A_PLAIN, 1); else STAR_GEMM_GO(A_PLAIN, 0);
+        if (rowaff || gelut) {
+          if constexpr (ALLEPI) {
+            if (rowaff) { if (geglu) STAR_GEMM_GO(A_PLAIN, 10); else STAR_GEMM_GO(A_PLAIN, 8); }
+            else STAR_GEMM_GO(A_PLAIN, 4);
+          } else return ctx->fail("gemm: this tile has no tanh-GELU / folded-LayerNorm epilogue (tiles 1-4 do)");
+        }
+        else if (geglu) STAR_GEMM_GO(A_PLAIN, 2); else if (res) STAR_GEMM_GO(A_PLAIN, 1); else STAR_GEMM_GO(A_PLAIN, 0);
       }
       break;
     case A_CONV3X3:
@@ -55,10 +62,10 @@ static int launch_gemm_f(Ctx* ctx, const GemmArgs& a) {
   return 0;
 }
 
-template <class T, int BM, int BN, int WM, int WN, int MINW, bool STAGGER = false, int PIPE = 0>
+template <class T, int BM, int BN, int WM, int WN, int MINW, bool STAGGER = false, int PIPE = 0, bool ALLEPI = false>
 static int launch_gemm_t(Ctx* ctx, const GemmArgs& a) {
   if (a.epi & EPI_OUT_F32) return launch_gemm_f<T, BM, BN, WM, WN, MINW, true, false, 0>(ctx, a);
-  return launch_gemm_f<T, BM, BN, WM, WN, MINW, false, STAGGER, PIPE>(ctx, a);
+  return launch_gemm_f<T, BM, BN, WM, WN, MINW, false, STAGGER, PIPE, ALLEPI>(ctx, a);
 }
 
 #ifdef STAR_BENCH_VARIANTS
@@ -114,10 +121,10 @@ static int launch_gemm(Ctx* ctx, const GemmArgs& a) {
   switch (tile) {
     // 8 waves per workgroup (2 per SIMD, <= 256 VGPRs each; 192 / 236 used, no spills): measured 1.3-3.6x faster than
     // 4-wave variants of the same tiles on the K = 320 layers (profiles/r01_gemm_tile_sweep.txt)
-    case 1: return launch_gemm_t<T, 256, 256, 4, 2, 2>(ctx, a);
-    case 2: return launch_gemm_t<T, 256, 320, 4, 2, 2>(ctx, a);
-    case 3: return launch_gemm_t<T, 128, 128, 2, 2, 2>(ctx, a);
-    case 4: return launch_gemm_t<T, 256, 128, 4, 1, 1>(ctx, a);
+    case 1: return launch_gemm_t<T, 256, 256, 4, 2, 2, false, 0, true>(ctx, a);
+    case 2: return launch_gemm_t<T, 256, 320, 4, 2, 2, false, 0, true>(ctx, a);
+    case 3: return launch_gemm_t<T, 128, 128, 2, 2, 2, false, 0, true>(ctx, a);
+    case 4: return launch_gemm_t<T, 256, 128, 4, 1, 1, false, 0, true>(ctx, a);
 #ifdef STAR_BENCH_VARIANTS   // A/B experiments of round 1 / 2 that lost to the tiles above (profiles/r01_gemm_ablation.txt, r02_gemm8_ablation.txt)
     case 5: return launch_gemm_t<T, 256, 256, 4, 2, 2, true>(ctx, a);   // staggered wave groups (A/B)
     // (the 256x320 tile has no room for the carried fragments: 730+ VGPR spills when staggered)
