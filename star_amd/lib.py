@@ -18,7 +18,7 @@ DEFAULT_LIB = os.path.join(_HERE, "libstar_hip.so")
 
 F16, BF16, F32 = 0, 1, 2
 A_PLAIN, A_CONV3X3, A_CONV3X3_UP, A_TCONV3 = 0, 1, 2, 3
-EPI_BIAS, EPI_RES, EPI_GEGLU, EPI_OUT_F32 = 1, 2, 4, 8
+EPI_BIAS, EPI_RES, EPI_GEGLU, EPI_OUT_F32, EPI_GELU_TANH = 1, 2, 4, 8, 16
 
 _TORCH2STAR = {torch.float16: F16, torch.bfloat16: BF16, torch.float32: F32}
 _STAR2TORCH = {v: k for k, v in _TORCH2STAR.items()}
@@ -208,7 +208,7 @@ class Context:
 
     # ------------------------------------------------------------------ kernels
     def gemm(self, A, W, bias=None, res=None, out=None, *, mode=A_PLAIN, M=None, conv=None, temporal=None,
-             geglu=False, out_f32=False, force_tile=0, up_crop=1):
+             geglu=False, out_f32=False, force_tile=0, up_crop=1, gelu_tanh=False):
         """out[M, N] = epilogue(A' @ W^T).  A: [rows, lda] activations (channels-last tokens);
         W: [N, K]; conv=(NB,H,Wd,Cin,Ho,Wo,stride,pad_t,pad_l); temporal=(F,HW,Cin)."""
         self._chk_tensor(A, self.dtype); self._chk_tensor(W, self.dtype)
@@ -238,7 +238,7 @@ class Context:
         d.lda, d.ldc = A.stride(0), out.stride(0)
         d.ldr = res.stride(0) if res is not None else 0
         d.epi = (EPI_BIAS if bias is not None else 0) | (EPI_RES if res is not None else 0) | \
-                (EPI_GEGLU if geglu else 0) | (EPI_OUT_F32 if out_f32 else 0)
+                (EPI_GEGLU if geglu else 0) | (EPI_OUT_F32 if out_f32 else 0) | (EPI_GELU_TANH if gelu_tanh else 0)
         d.force_tile = force_tile
         self._check(self.lib.gemm(self.h, ctypes.byref(d)), "gemm")
         return out

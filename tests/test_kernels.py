@@ -114,6 +114,30 @@ def test_gemm_geglu(ctx, dtype, M, K, Nh):
     assert_close(out, ref, dtype, what="geglu")
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 192, 128), (515, 640, 192), (77, 1280, 256)])
+def test_gemm_gelu_tanh(ctx, dtype, M, N, K):
+    """tanh-GELU epilogue (STAR_EPI_GELU_TANH: the MLP activation of the CogVideoX DiT block, sat's gelu_impl) on the auto tiles."""
+    g = torch.Generator().manual_seed(M + N)
+    A = torch.randn(M, K, generator=g).to(dtype)
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dtype)
+    b = torch.randn(N, generator=g)
+    ref = F.gelu(A.float() @ W.float().T + b, approximate="tanh")
+    out = ctx.gemm(dev(ctx, A), dev(ctx, W), bias=dev(ctx, b), gelu_tanh=True)
+    assert_close(out, ref, dtype, what="gelu_tanh")
+    with pytest.raises(L.StarError):      # the flavour exists for plain-A layers without a residual only
+        ctx.gemm(dev(ctx, A), dev(ctx, W), bias=dev(ctx, b), res=dev(ctx, torch.zeros(M, N).to(dtype)), gelu_tanh=True)
+
+
+def test_gather_offset_guard(ctx, dtype):
+    """the implicit-GEMM gathers address their input with 32-bit offsets from a per-tile base (a few image rows): an image row
+    pitch that cannot fit must be refused by the launcher, not wrapped (the check runs before anything is launched)."""
+    A = torch.zeros(64, 64).to(dtype)
+    W = torch.zeros(64, 9 * 64).to(dtype)
+    with pytest.raises(L.StarError, match="32-bit gather offsets"):
+        ctx.gemm(dev(ctx, A), dev(ctx, W), mode=L.A_CONV3X3, conv=(1, 1, 1 << 22, 64, 1, 1 << 22, 1, 1, 1),
+                 out=dev(ctx, torch.zeros(8, 64).to(dtype)))
+
+
 CONV_CASES = [  # NB, Cin, H, W, Cout
     (2, 64, 10, 8, 96), (1, 128, 18, 16, 64), (3, 320, 10, 8, 320),
 ]
