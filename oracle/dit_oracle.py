@@ -127,3 +127,64 @@ def dit_block_forward(sd, cfg, layer, x, emb, text_len, T, H, W):
     img = img + gate_mlp.unsqueeze(1) * e[:, text_len:]                                                         # :561
     txt = txt + t_gate_mlp.unsqueeze(1) * e[:, :text_len]                                                       # :562
     return torch.cat([txt, img], dim=1)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The whole DiffusionTransformer.forward (dit_video_concat.py:791-817) around the blocks: timestep embedding + time_embed MLP
+# (:688-693, sgm timestep_embedding), patch embedding + text projection (:51-76), layers, sat's final_layernorm (BaseTransformer:
+# applied to the layer stack's output before the final_forward hook -- sat internals, PARITY UNPINNED), FinalLayerMixin (:395-410).
+def random_dit_model_state_dict(cfg, in_channels=8, out_channels=8, patch=2, text_hidden=64, seed=0):
+    sd = random_dit_state_dict(cfg, seed)
+    g = torch.Generator().manual_seed(seed + 1000)
+    rn = lambda *s, std=1.0: torch.randn(*s, generator=g) * std
+    D, E = cfg.hidden, cfg.time_embed_dim
+    sd["time_embed.0.weight"], sd["time_embed.0.bias"] = rn(E, D, std=D ** -0.5), rn(E, std=0.1)
+    sd["time_embed.2.weight"], sd["time_embed.2.bias"] = rn(E, E, std=E ** -0.5), rn(E, std=0.1)
+    kin = 2 * in_channels * patch * patch
+    sd["mixins.patch_embed.proj_sr.weight"], sd["mixins.patch_embed.proj_sr.bias"] = rn(D, 2 * in_channels, patch, patch, std=kin ** -0.5), rn(D, std=0.1)
+    sd["mixins.patch_embed.text_proj.weight"], sd["mixins.patch_embed.text_proj.bias"] = rn(D, text_hidden, std=text_hidden ** -0.5), rn(D, std=0.1)
+    for k in ("transformer.final_layernorm", "mixins.final_layer.norm_final"):
+        sd[k + ".weight"], sd[k + ".bias"] = 1.0 + rn(D, std=0.1), rn(D, std=0.1)
+    sd["mixins.final_layer.linear.weight"], sd["mixins.final_layer.linear.bias"] = rn(patch * patch * out_channels, D, std=D ** -0.5), rn(patch * patch * out_channels, std=0.1)
+    sd["mixins.final_layer.adaLN_modulation.1.weight"], sd["mixins.final_layer.adaLN_modulation.1.bias"] = rn(2 * D, E, std=0.3 * E ** -0.5), rn(2 * D, std=0.2)
+    return sd
+
+
+def dit_forward(sd, cfg, x, timesteps, context, out_channels, patch=2):
+    """x [1, T, 2C, H, W], timesteps [1], context [1, n_text, text_hidden] -> [1, T, C_out, H, W] (fp32)."""
+    D = cfg.hidden
+    half = D // 2
+    freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
+    args = timesteps[:, None].float() * freqs[None]
+    emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+    emb = F.linear(F.silu(F.linear(emb, sd["time_embed.0.weight"], sd["time_embed.0.bias"])), sd["time_embed.2.weight"], sd["time_embed.2.bias"])
+    _, T, C2, H, W = x.shape
+    hid = patch_embed(sd, x, context, patch)
+    h, w = H // patch, W // patch
+    n_text = context.shape[1]
+    for i in range(cfg.n_layers):
+        hid = dit_block_forward(sd, cfg, i, hid, emb, n_text, T, h, w)
+    hid = F.layer_norm(hid, (D,), sd["transformer.final_layernorm.weight"], sd["transformer.final_layernorm.bias"], cfg.ln_eps)
+    return final_layer(sd, cfg, hid, emb, n_text, T, h, w, out_channels, patch)
+
+
+def patch_embed(sd, x, context, patch=2):
+    """ImagePatchEmbeddingMixin.word_embedding_forward (dit_video_concat.py:51-76): Conv2d(k = s = patch) per frame, tokens in
+    (t h w) order behind the projected text tokens.  Pinned to the reference's own mixin by tests/golden/dit_block.pt."""
+    _, T, C2, H, W = x.shape
+    e = F.conv2d(x[0].float(), sd["mixins.patch_embed.proj_sr.weight"], sd["mixins.patch_embed.proj_sr.bias"], stride=patch)   # (t, d, h/p, w/p)
+    e = e.flatten(2).transpose(1, 2).reshape(1, -1, e.shape[1])
+    txt = F.linear(context.float(), sd["mixins.patch_embed.text_proj.weight"], sd["mixins.patch_embed.text_proj.bias"])
+    return torch.cat([txt, e], dim=1)
+
+
+def final_layer(sd, cfg, hid, emb, n_text, T, h, w, out_channels, patch=2):
+    """FinalLayerMixin.final_forward (:395-410) + unpatchify (:353-369) on the video tokens.  Pinned like patch_embed."""
+    D = cfg.hidden
+    v = hid[:, n_text:]
+    shift, scale = F.linear(F.silu(emb), sd["mixins.final_layer.adaLN_modulation.1.weight"], sd["mixins.final_layer.adaLN_modulation.1.bias"]).chunk(2, dim=1)
+    v = F.layer_norm(v, (D,), sd["mixins.final_layer.norm_final.weight"], sd["mixins.final_layer.norm_final.bias"], 1e-6)
+    v = v * (1 + scale.unsqueeze(1)) + shift.unsqueeze(1)
+    v = F.linear(v, sd["mixins.final_layer.linear.weight"], sd["mixins.final_layer.linear.bias"])
+    c, p = out_channels, patch
+    return v.reshape(1, T, h, w, c, p, p).permute(0, 1, 4, 2, 5, 3, 6).reshape(1, T, c, h * p, w * p)

@@ -135,10 +135,31 @@ def main():
     shell = types.SimpleNamespace(layers={layer_id: layer}, layernorm_order="pre")
     object.__setattr__(ada, "transformer", shell)
     out = ada.layer_forward(x.clone(), None, text_length=text_len, layer_id=layer_id, emb=emb)
+    # ---- the reference's patch embedding and final layer (ImagePatchEmbeddingMixin :23-83, FinalLayerMixin :372-415, unpatchify)
+    C, p_, th = 8, 2, 64
+    msd = O.random_dit_model_state_dict(cfg, in_channels=C, out_channels=C, patch=p_, text_hidden=th, seed=0)
+    gm = torch.Generator().manual_seed(3)
+    Hl, Wl, n_text = 6, 8, 5
+    xm = torch.randn(1, T, 2 * C, Hl, Wl, generator=gm)
+    cm = torch.randn(1, n_text, th, generator=gm)
+    pe = dit.ImagePatchEmbeddingMixin(in_channels=C, hidden_size=D, patch_size=p_, text_hidden_size=th)
+    pe.load_state_dict({k[len("mixins.patch_embed."):]: v for k, v in msd.items() if k.startswith("mixins.patch_embed.")})
+    pe_out = pe.word_embedding_forward(None, images=xm, encoder_outputs=cm)
+    fl = dit.FinalLayerMixin(hidden_size=D, time_embed_dim=cfg.time_embed_dim, patch_size=p_, out_channels=C, latent_width=Wl,
+                             latent_height=Hl, elementwise_affine=True)
+    fl.load_state_dict({k[len("mixins.final_layer."):]: v for k, v in msd.items() if k.startswith("mixins.final_layer.")})
+    hid_m = torch.randn(1, n_text + T * (Hl // p_) * (Wl // p_), D, generator=gm)
+    emb_m = torch.randn(1, cfg.time_embed_dim, generator=gm)
+    fl_out = fl.final_forward(hid_m, text_length=n_text, emb=emb_m)
+    d_pe = float((O.patch_embed(msd, xm, cm, p_) - pe_out).abs().max())
+    d_fl = float((O.final_layer(msd, cfg, hid_m, emb_m, n_text, T, Hl // p_, Wl // p_, C, p_) - fl_out).abs().max())
     path = os.path.join(ROOT, "tests", "golden", "dit_block.pt")
     torch.save({"cfg": dict(hidden=D, heads=heads, time_embed_dim=cfg.time_embed_dim, n_layers=cfg.n_layers, ln_eps=cfg.ln_eps),
                 "geometry": (text_len, T, H, W), "layer": layer_id, "sd_seed": 0, "in_seed": 1, "out": out.float().clone(),
-                "rope_cos": rope.freqs_cos.clone(), "rope_sin": rope.freqs_sin.clone()}, path)
+                "rope_cos": rope.freqs_cos.clone(), "rope_sin": rope.freqs_sin.clone(),
+                "model_parts": {"C": C, "patch": p_, "text_hidden": th, "geometry": (T, Hl, Wl, n_text), "seed": 3,
+                                "patch_embed_out": pe_out.float().clone(), "final_layer_out": fl_out.float().clone()}}, path)
+    print("patch embedding / final layer: restatement vs reference max abs diff %.3e / %.3e" % (d_pe, d_fl))
     ours = O.dit_block_forward(sd, cfg, layer_id, x, emb, text_len, T, H, W)
     print("saved", path, "out rms %.4f" % float(out.pow(2).mean().sqrt()), "| restatement vs reference: max abs diff %.3e" % float((ours - out).abs().max()))
 

@@ -27,6 +27,25 @@ def test_oracle_matches_reference_mixin():
     assert float((cos - g["rope_cos"]).abs().max()) <= 1e-6 and float((sin - g["rope_sin"]).abs().max()) <= 1e-6
 
 
+def test_oracle_model_parts_match_reference_mixins():
+    """patch embedding + text projection and the final layer + unpatchify of the restatement == ImagePatchEmbeddingMixin /
+    FinalLayerMixin executed from /root/reference (fixture)."""
+    g = torch.load(GOLD)
+    cfg = O.DitConfig(**g["cfg"])
+    mp = g["model_parts"]
+    C, p, th = mp["C"], mp["patch"], mp["text_hidden"]
+    T, H, W, n_text = mp["geometry"]
+    sd = O.random_dit_model_state_dict(cfg, in_channels=C, out_channels=C, patch=p, text_hidden=th, seed=0)
+    gm = torch.Generator().manual_seed(mp["seed"])
+    x = torch.randn(1, T, 2 * C, H, W, generator=gm)
+    ctxt = torch.randn(1, n_text, th, generator=gm)
+    assert float((O.patch_embed(sd, x, ctxt, p) - mp["patch_embed_out"]).abs().max()) <= 2e-5
+    hid = torch.randn(1, n_text + T * (H // p) * (W // p), cfg.hidden, generator=gm)
+    emb = torch.randn(1, cfg.time_embed_dim, generator=gm)
+    out = O.final_layer(sd, cfg, hid, emb, n_text, T, H // p, W // p, C, p)
+    assert float((out - mp["final_layer_out"]).abs().max()) <= 2e-5
+
+
 def _run(backend, dtype, emu_lib, cfg, geom, layer, tol):
     from star_amd.modules.dit import DiTBlocks
     text_len, T, H, W = geom
@@ -56,3 +75,28 @@ def test_dit_block_wide():
     cfg = O.DitConfig(hidden=1024, heads=16, time_embed_dim=512, n_layers=1)
     rel = _run("hip", torch.float16, None, cfg, (226, 3, 12, 20), 0, 4e-3)
     print(f"DiT block hidden 1024: rel rms {rel:.2e}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_dit_model_forward(backend, dtype, emu_lib):
+    """DiffusionTransformer.forward end to end at reduced width (2 layers, hidden 128): timestep embedding, patch embedding of the
+    (latent | LQ latent) pair, text projection, the blocks, final LayerNorms + adaLN + Linear + unpatchify, against the fp32
+    restatement."""
+    from star_amd.modules.dit import DiffusionTransformer
+    cfg = O.SMALL_DIT_CONFIG
+    C, p, th = 8, 2, 64
+    sd = O.random_dit_model_state_dict(cfg, in_channels=C, out_channels=C, patch=p, text_hidden=th, seed=0)
+    g = torch.Generator().manual_seed(3)
+    T, H, W, n_text = 2, 6, 8, 5
+    x = torch.randn(1, T, 2 * C, H, W, generator=g)
+    ctxt = torch.randn(1, n_text, th, generator=g)
+    ts = torch.tensor([417.0])
+    net = DiffusionTransformer(cfg.hidden, cfg.heads, cfg.time_embed_dim, cfg.n_layers, in_channels=C, out_channels=C, patch_size=p,
+                               text_hidden=th, ln_eps=cfg.ln_eps, dtype=dtype, library=emu_lib if backend == "emu" else None).load_state_dict(sd)
+    dev = net.blocks.ctx.torch_device
+    out = net(x.to(dev), ts.to(dev), ctxt.to(dev)).float().cpu()
+    ref = O.dit_forward(sd, cfg, x.to(dtype).float(), ts, ctxt.to(dtype).float(), C, p)
+    assert out.shape == ref.shape == (1, T, C, H, W)
+    rel = float((out - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+    assert torch.isfinite(out).all() and rel <= (6e-3 if dtype == torch.float16 else 4e-2), f"DiT forward rel rms {rel:.3e}"
