@@ -1,0 +1,179 @@
+// gemm_impl.h -- tile selection + launch for gemm_kernel (see gemm.h), instantiated once per storage type in gemm_f16.cpp /
+// gemm_bf16.cpp (two translation units: gemm_kernel has ~100 instantiations per type and is the longest compile of the build).
+#pragma once
+#include "ops.h"
+#include "gemm.h"
+#ifdef STAR_BENCH_VARIANTS
+#include "gemm8.h"
+#endif
+
+namespace star {
+
+// ALLEPI: also instantiate the tanh-GELU and folded-LayerNorm epilogue flavours (the auto-selected tiles 1-4 only: every
+// flavour is one more kernel per tile, mode and dtype, and gemm.cpp is the longest compile of the build)
+template <class T, int BM, int BN, int WM, int WN, int MINW, bool F32OUT, bool STAGGER, int PIPE = 0, bool ALLEPI = false>
+static int launch_gemm_f(Ctx* ctx, const GemmArgs& a) {
+  GemmParams p{};
+  p.A = a.A; p.W = a.W; p.C = a.C; p.bias = a.bias; p.res = a.res; p.zero_page = ctx->zero_page;
+  p.M = a.M; p.N = a.N; p.K = a.K; p.lda = a.lda; p.ldc = a.ldc; p.ldr = a.ldr;
+  p.H = a.H; p.Wd = a.Wd; p.Cin = a.Cin; p.Ho = a.Ho; p.Wo = a.Wo; p.stride = a.stride; p.pad_t = a.pad_t; p.pad_l = a.pad_l;
+  p.HW = a.HW; p.F = a.F; p.up_crop = a.up_crop; p.epi = a.epi;
+  p.rowab = a.rowab; p.colsum = a.colsum;
+  p.tiles_m = (a.M + BM - 1) / BM;
+  p.tiles_n = (a.N + BN - 1) / BN;
+  // 2 stages x 64 k, or PIPE ring slots x 32 k; never less than the epilogue's per-wave staging blocks
+  constexpr size_t smem_loop = PIPE ? (size_t)PIPE * (BM + BN) * 64 : 2 * (size_t)(BM + BN) * 128;
+  constexpr size_t smem_epi = (size_t)WM * WN * 32 * (BN / WN * 2 + 8);
+  static_assert(smem_epi <= smem_loop, "the epilogue's staging blocks must fit under the bias slice");
+  constexpr size_t smem = smem_loop + 2 * (size_t)BN * sizeof(float);   // + this tile's bias slice (+ column sums of a folded LayerNorm)
+  unsigned nwg = (unsigned)(p.tiles_m * p.tiles_n);
+  if (a.persist > 0 && nwg > (unsigned)a.persist) nwg = (unsigned)a.persist;   // persistent tile walk (gemm.h)
+  dim3 grid(nwg), block(WM * WN * 64);
+  // 16-bit epilogue flavour (compile-time in the kernel): plain / + residual / GEGLU (plain-A layers only, no residual)
+  const bool res = !F32OUT && (a.epi & EPI_RES), geglu = !F32OUT && (a.epi & EPI_GEGLU), gelut = !F32OUT && (a.epi & EPI_GELU_TANH);
+  if ((geglu || gelut) && (res || a.mode != A_PLAIN || (geglu && gelut))) return ctx->fail("gemm: GEGLU / tanh-GELU are for plain-A layers without a residual");
+  const bool rowaff = !F32OUT && (a.epi & EPI_ROWAFF);
+  if (rowaff && (res || gelut || a.mode != A_PLAIN || !a.rowab || !a.colsum || !(a.epi & EPI_BIAS)))
+    return ctx->fail("gemm: the folded-LayerNorm epilogue is for plain-A layers without a residual and needs rowab, colsum and bias");
+#define STAR_GEMM_GO(MODE, EF) STAR_LAUNCH((gemm_kernel<T, BM, BN, WM, WN, MODE, MINW, F32OUT, STAGGER, 0, PIPE, EF>), grid, block, smem, ctx->stream, p)
+  switch (a.mode) {
+    case A_PLAIN:
+      if constexpr (F32OUT) STAR_GEMM_GO(A_PLAIN, 0);
+      else {
+        if (rowaff || gelut) {
+          if constexpr (ALLEPI) {
+            if (rowaff) { if (geglu) STAR_GEMM_GO(A_PLAIN, 10); else STAR_GEMM_GO(A_PLAIN, 8); }
+            else STAR_GEMM_GO(A_PLAIN, 4);
+          } else return ctx->fail("gemm: this tile has no tanh-GELU / folded-LayerNorm epilogue (tiles 1-4 do)");
+        }
+        else if (geglu) STAR_GEMM_GO(A_PLAIN, 2); else if (res) STAR_GEMM_GO(A_PLAIN, 1); else STAR_GEMM_GO(A_PLAIN, 0);
+      }
+      break;
+    case A_CONV3X3:
+      if constexpr (F32OUT) STAR_GEMM_GO(A_CONV3X3, 0); else { if (res) STAR_GEMM_GO(A_CONV3X3, 1); else STAR_GEMM_GO(A_CONV3X3, 0); }
+      break;
+    case A_CONV3X3_UP:
+      if constexpr (F32OUT) STAR_GEMM_GO(A_CONV3X3_UP, 0); else { if (res) STAR_GEMM_GO(A_CONV3X3_UP, 1); else STAR_GEMM_GO(A_CONV3X3_UP, 0); }
+      break;
+    case A_TCONV3:
+      if constexpr (F32OUT) STAR_GEMM_GO(A_TCONV3, 0); else { if (res) STAR_GEMM_GO(A_TCONV3, 1); else STAR_GEMM_GO(A_TCONV3, 0); }
+      break;
+    default: return ctx->fail("gemm: bad A mode");
+  }
+#undef STAR_GEMM_GO
+  return 0;
+}
+
+template <class T, int BM, int BN, int WM, int WN, int MINW, bool STAGGER = false, int PIPE = 0, bool ALLEPI = false>
+static int launch_gemm_t(Ctx* ctx, const GemmArgs& a) {
+  if (a.epi & EPI_OUT_F32) return launch_gemm_f<T, BM, BN, WM, WN, MINW, true, false, 0>(ctx, a);
+  return launch_gemm_f<T, BM, BN, WM, WN, MINW, false, STAGGER, PIPE, ALLEPI>(ctx, a);
+}
+
+#ifdef STAR_BENCH_VARIANTS
+// persistent phase-interleaved kernel (gemm8.h): one workgroup per CU walks its output tiles
+template <class T, bool RES, int ABL = 0>
+static int launch_gemm8_r(Ctx* ctx, const GemmArgs& a, int grid_cap) {
+  GemmParams p{};
+  p.A = a.A; p.W = a.W; p.C = a.C; p.bias = a.bias; p.res = a.res; p.zero_page = ctx->zero_page;
+  p.M = a.M; p.N = a.N; p.K = a.K; p.lda = a.lda; p.ldc = a.ldc; p.ldr = a.ldr;
+  p.H = a.H; p.Wd = a.Wd; p.Cin = a.Cin; p.Ho = a.Ho; p.Wo = a.Wo; p.stride = a.stride; p.pad_t = a.pad_t; p.pad_l = a.pad_l;
+  p.HW = a.HW; p.F = a.F; p.up_crop = a.up_crop; p.epi = a.epi;
+  p.tiles_m = (a.M + G8::BM - 1) / G8::BM;
+  p.tiles_n = (a.N + G8::BN - 1) / G8::BN;
+  const int nblk = p.tiles_m * p.tiles_n;
+  const int g = nblk <= grid_cap ? nblk : grid_cap;   // grid_cap is a multiple of 8 (XCD affinity of the tile walk)
+  dim3 grid((unsigned)g), block(G8::NT);
+  constexpr size_t smem = G8::SMEM_TOTAL;
+  switch (a.mode) {
+    case A_PLAIN: STAR_LAUNCH((gemm8_kernel<T, A_PLAIN, RES, ABL>), grid, block, smem, ctx->stream, p); break;
+    case A_CONV3X3: STAR_LAUNCH((gemm8_kernel<T, A_CONV3X3, RES, ABL>), grid, block, smem, ctx->stream, p); break;
+    case A_CONV3X3_UP: STAR_LAUNCH((gemm8_kernel<T, A_CONV3X3_UP, RES, ABL>), grid, block, smem, ctx->stream, p); break;
+    case A_TCONV3: STAR_LAUNCH((gemm8_kernel<T, A_TCONV3, RES, ABL>), grid, block, smem, ctx->stream, p); break;
+    default: return ctx->fail("gemm8: bad A mode");
+  }
+  return 0;
+}
+template <class T>
+static int launch_gemm8(Ctx* ctx, const GemmArgs& a, int grid_cap) {
+  return (a.epi & EPI_RES) ? launch_gemm8_r<T, true>(ctx, a, grid_cap) : launch_gemm8_r<T, false>(ctx, a, grid_cap);
+}
+
+#endif
+
+template <class T>
+static int launch_gemm(Ctx* ctx, const GemmArgs& a) {
+  int tile = a.force_tile;
+  if (tile >= 100 && tile < 1000) {   // A/B: 1xx = tile xx walked by 256 persistent workgroups, 2xx by 512
+    GemmArgs b = a;
+    b.force_tile = tile % 100;
+    b.persist = 256 * (tile / 100);
+    return launch_gemm<T>(ctx, b);
+  }
+  if (!tile) {
+    const bool geglu = (a.epi & EPI_GEGLU) != 0;
+    if (a.M <= 4096 && a.N <= 1024) tile = 3;                          // small problems: more, smaller tiles
+    else if (!geglu && a.N % 320 == 0) tile = 2;                        // 320 / 640 / 960 / 1280 / 1920-wide layers
+    // (rounds 1-2 sent the short-K GEGLU layers to tile 9, two 4-wave workgroups per CU hiding each other's GELU epilogue;
+    // with the erfc-form GELU and the compile-time epilogue the 8-wave 256x256 tile is 7 % faster there: 1.89 vs 2.04 ms at
+    // 843264 x 2560 x 320, profiles/r02_gemm_tiles_after_valu.txt)
+    else if (a.N <= 128) tile = 4;
+    else tile = 1;
+  }
+  switch (tile) {
+    // 8 waves per workgroup (2 per SIMD, <= 256 VGPRs each; 192 / 236 used, no spills): measured 1.3-3.6x faster than
+    // 4-wave variants of the same tiles on the K = 320 layers (profiles/r01_gemm_tile_sweep.txt)
+    case 1: return launch_gemm_t<T, 256, 256, 4, 2, 2, false, 0, true>(ctx, a);
+    case 2: return launch_gemm_t<T, 256, 320, 4, 2, 2, false, 0, true>(ctx, a);
+    case 3: return launch_gemm_t<T, 128, 128, 2, 2, 2, false, 0, true>(ctx, a);
+    case 4: return launch_gemm_t<T, 256, 128, 4, 1, 1, false, 0, true>(ctx, a);
+#ifdef STAR_BENCH_VARIANTS   // A/B experiments of round 1 / 2 that lost to the tiles above (profiles/r01_gemm_ablation.txt, r02_gemm8_ablation.txt)
+    case 5: return launch_gemm_t<T, 256, 256, 4, 2, 2, true>(ctx, a);   // staggered wave groups (A/B)
+    // (the 256x320 tile has no room for the carried fragments: 730+ VGPR spills when staggered)
+    case 7: return launch_gemm_t<T, 256, 256, 4, 2, 2, false, 4>(ctx, a);   // pipelined main loop (ring of 4 x 32-k slots)
+    case 8: return launch_gemm_t<T, 256, 320, 4, 2, 2, false, 4>(ctx, a);
+    case 14: return launch_gemm_t<T, 256, 256, 2, 2, 1>(ctx, a);   // 4 waves x (128 x 128), one wave per SIMD, accumulators in AGPRs: 1/3 fewer LDS fragment reads
+#endif
+    // two independent 4-wave workgroups per CU on a 128 x 320 tile (two 32-deep LDS slots, 56 KB each): one group's prologue /
+    // epilogue / store drain runs beside the other's MFMAs -- for the short-K layers, whose tiles spend most of their time
+    // outside the K loop
+    case 10: return launch_gemm_t<T, 128, 320, 2, 2, 2, false, 2>(ctx, a);
+    // two independent 4-wave workgroups per CU (72 KB of LDS each): one group's epilogue and DMA latency hide behind the
+    // other group's MFMA burst (auto-selected for the short-K GEGLU layers)
+    case 9: return launch_gemm_t<T, 128, 256, 2, 2, 2, false, 3>(ctx, a);
+#ifdef STAR_BENCH_VARIANTS
+    // persistent phase-interleaved kernel (gemm8.h): correct and race-free on hardware, not faster than the 2-stage tiles on
+    // random operands (power-limited; profiles/r02_gemm8_ablation.txt).  fp32 output stays on the 2-stage tiles.
+    case 20: if (a.epi & EPI_OUT_F32) return launch_gemm_t<T, 256, 256, 4, 2, 2>(ctx, a); return launch_gemm8<T>(ctx, a, 256);
+    case 21: if (a.epi & EPI_OUT_F32) return launch_gemm_t<T, 256, 256, 4, 2, 2>(ctx, a); return launch_gemm8<T>(ctx, a, 8);   // 8 workgroups (tests: several output tiles per workgroup)
+    case 31: return launch_gemm8_r<T, false, 1>(ctx, a, 256);   // timing ablations of gemm8 (garbage results)
+    case 32: return launch_gemm8_r<T, false, 2>(ctx, a, 256);
+    case 33: return launch_gemm8_r<T, false, 3>(ctx, a, 256);
+    case 34: return launch_gemm8_r<T, false, 4>(ctx, a, 256);
+    case 35: return launch_gemm8_r<T, false, 5>(ctx, a, 256);
+    case 36: return launch_gemm8_r<T, false, 6>(ctx, a, 256);
+    case 37: return launch_gemm8_r<T, false, 7>(ctx, a, 256);
+    case 38: return launch_gemm8_r<T, false, 8>(ctx, a, 256);
+    case 39: return (a.epi & EPI_RES) ? launch_gemm8_r<T, true, 9>(ctx, a, 256) : launch_gemm8_r<T, false, 9>(ctx, a, 256);   // gemm8 without the stagger (correct results)
+#endif
+  }
+#ifdef STAR_BENCH_VARIANTS
+  if (tile >= 11 && tile <= 16 && tile != 14 && a.mode == A_PLAIN && !(a.epi & EPI_OUT_F32)) {   // ablation probes of the 256x256 main loop
+    GemmParams p{};
+    p.A = a.A; p.W = a.W; p.C = a.C; p.bias = a.bias; p.res = a.res; p.zero_page = ctx->zero_page;
+    p.M = a.M; p.N = a.N; p.K = a.K; p.lda = a.lda; p.ldc = a.ldc; p.ldr = a.ldr; p.epi = a.epi;
+    p.tiles_m = (a.M + 255) / 256; p.tiles_n = (a.N + 255) / 256;
+    dim3 grid((unsigned)(p.tiles_m * p.tiles_n)), block(512);
+    const size_t smem = 2 * (size_t)512 * 128 + 256 * sizeof(float);
+    if (tile == 11) STAR_LAUNCH((gemm_kernel<T, 256, 256, 4, 2, A_PLAIN, 2, false, false, 1>), grid, block, smem, ctx->stream, p);
+    if (tile == 12) STAR_LAUNCH((gemm_kernel<T, 256, 256, 4, 2, A_PLAIN, 2, false, false, 2>), grid, block, smem, ctx->stream, p);
+    if (tile == 13) STAR_LAUNCH((gemm_kernel<T, 256, 256, 4, 2, A_PLAIN, 2, false, false, 3>), grid, block, smem, ctx->stream, p);
+    if (tile == 15) STAR_LAUNCH((gemm_kernel<T, 256, 256, 4, 2, A_PLAIN, 2, false, false, 4>), grid, block, smem, ctx->stream, p);   // no K loop at all
+    if (tile == 16) STAR_LAUNCH((gemm_kernel<T, 256, 256, 4, 2, A_PLAIN, 2, false, false, 5>), grid, block, smem, ctx->stream, p);   // no global stores
+    return 0;
+  }
+#endif
+  return ctx->fail("gemm: bad tile id (experimental tiles exist only in the bench build)");
+}
+
+}  // namespace star
