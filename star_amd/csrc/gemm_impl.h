@@ -10,7 +10,7 @@
 namespace star {
 
 // ALLEPI: also instantiate the tanh-GELU and folded-LayerNorm epilogue flavours (the auto-selected tiles 1-4 only: every
-// flavour is one more kernel per tile, mode and dtype, and gemm.cpp is the longest compile of the build)
+// flavour is one more kernel per tile, mode and dtype, and these are the longest compiles of the build)
 template <class T, int BM, int BN, int WM, int WN, int MINW, bool F32OUT, bool STAGGER, int PIPE = 0, bool ALLEPI = false>
 static int launch_gemm_f(Ctx* ctx, const GemmArgs& a) {
   GemmParams p{};

@@ -11,7 +11,7 @@ ctxs = [L.Context(0, dt, L.Library(os.path.abspath(p))) for p in sys.argv[1:3]]
 PERSIST_B = int(os.environ.get("AB_PERSIST_B", "0"))   # build B walks its tiles with 256 * PERSIST_B persistent workgroups
 
 
-def auto_tile(M, N, K, geglu=False, plain=True):   # gemm.cpp: launch_gemm
+def auto_tile(M, N, K, geglu=False, plain=True):   # gemm_impl.h: launch_gemm
     if M <= 4096 and N <= 1024: return 3
     if not geglu and N % 320 == 0: return 2
     if geglu and K <= 320 and plain: return 9
