@@ -18,6 +18,7 @@ emu: tools/hostemu/libstar_emu.so
 # attention kernels: no NaN-canonicalising v_max in front of every fmaxf on MFMA outputs (39 extra VALU per key tile);
 # masked scores are finite (-1e30 / -30000), so NaNs can only come from NaN inputs and propagate either way
 build/hip/attn.o: HIPFLAGS += -fno-honor-nans -fno-slp-vectorize
+build/hip/attn7.o: HIPFLAGS += -fno-honor-nans -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form
 build/hip/%.o: $(CSRC)/%.cpp $(wildcard $(CSRC)/*.h) include/star_hip.h
 	@mkdir -p build/hip
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
@@ -37,6 +38,7 @@ tools/hostemu/libstar_emu.so: $(EMU_OBJS)
 BENCH_OBJS := $(patsubst $(CSRC)/%.cpp,build/bench/%.o,$(SRCS))
 bench: tools/bench/libstar_hip_bench.so
 build/bench/attn.o: HIPFLAGS += -fno-honor-nans -fno-slp-vectorize
+build/bench/attn7.o: HIPFLAGS += -fno-honor-nans -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form
 build/bench/%.o: $(CSRC)/%.cpp $(wildcard $(CSRC)/*.h) include/star_hip.h
 	@mkdir -p build/bench
 	$(HIPCC) $(HIPFLAGS) -DSTAR_BENCH_VARIANTS=1 -c $< -o $@

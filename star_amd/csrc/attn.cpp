@@ -10,6 +10,9 @@
 
 namespace star {
 
+int launch_flash_v7(Ctx* ctx, const AttnParams& p, int nq, int pksum);   // attn7.cpp
+int launch_flash_v7_abl(Ctx* ctx, const AttnParams& p, int abl);
+
 template <class T>
 static int launch_flash(Ctx* ctx, const AttnArgs& a) {
   AttnParams p{};
@@ -42,6 +45,8 @@ static int launch_flash(Ctx* ctx, const AttnArgs& a) {
     return 0;
   }
 #ifdef STAR_BENCH_VARIANTS
+  if (a.variant == 40 || a.variant == 41) return launch_flash_v7(ctx, p, a.variant == 41 ? 3 : 2, a.Nk >= 1024 ? 1 : 0);   // attn7.h: one wave per SIMD, query-block pipeline
+  if (a.variant >= 50 && a.variant < 70) return launch_flash_v7_abl(ctx, p, a.variant - 50);
   if (a.variant == 33) {   // v5 with the augmented k-step as a full-depth 32x32x16 MFMA (the shipped kernel uses the half-depth 32x32x8 form)
     if constexpr (__is_same(T, f16)) { STAR_LAUNCH((flash_attn_v5_kernel<T, 1, 0>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p); return 0; }
     else { STAR_LAUNCH((flash_attn_v5_kernel<T, 0, 0>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p); return 0; }

@@ -217,6 +217,18 @@ STAR_DEV void glds16_su(const void* ubase, uint32_t lane_off, void* lds_wave_bas
                :: "s"(lds), "v"(lane_off), "s"(ubase) : "memory", "m0");
 #endif
 }
+// glds16 written out (per-lane 64-bit source pointer), for kernels whose LDS-DMA must stay invisible to hipcc: one compiler-visible
+// LDS-DMA anywhere in a kernel makes hipcc put s_waitcnt vmcnt(0) in front of the first LDS read behind every point where a DMA
+// may be pending -- which drains the hand-counted asm copies that run TILES ahead as well (attn7.h)
+STAR_DEV void glds16_v(const void* gsrc, void* lds_wave_base) {
+#ifdef STAR_HOSTEMU
+  glds16(gsrc, lds_wave_base);
+#else
+  const uint32_t lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds_wave_base;
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+               :: "s"(lds), "v"(gsrc) : "memory", "m0");
+#endif
+}
 STAR_DEV void glds_wait() {
 #ifndef STAR_HOSTEMU
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -279,6 +291,13 @@ STAR_DEV void wave_lds_fence() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
 }
+// a wait on the LDS / scalar-memory counter the compiler KNOWS about (it books builtin waits, not asm ones): placed where
+// nothing can still be in flight, it keeps hipcc from inserting its own conservative lgkmcnt(0) behind freshly issued reads
+#ifdef STAR_HOSTEMU
+#define STAR_WAIT_LGKM0()
+#else
+#define STAR_WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)
+#endif
 #ifdef STAR_HOSTEMU
 #define STAR_SETPRIO(n)
 #else
@@ -457,6 +476,23 @@ STAR_DEV int opaque_int(int v) {
 #endif
   return v;
 }
+// make a 32-bit value exist in a VGPR at this point of the instruction stream (no instruction): its producer cannot sink below,
+// its consumers cannot rise above
+template <class V>
+STAR_DEV V pin_here(V v) {
+#ifndef STAR_HOSTEMU
+  if constexpr (sizeof(V) == 4) {
+    uint32_t u = __builtin_bit_cast(uint32_t, v);
+    asm volatile("" : "+v"(u));
+    return __builtin_bit_cast(V, u);
+  } else {
+    asm volatile("" : "+v"(v));
+    return v;
+  }
+#else
+  return v;
+#endif
+}
 // tell the compiler a value is wave-uniform (v_readfirstlane); identity on the emulator
 STAR_DEV int wave_uniform(int v) {
 #ifdef STAR_HOSTEMU
@@ -477,6 +513,17 @@ STAR_DEV bool wave_any(bool pred) {
   return __any(pred ? 1 : 0) != 0;
 #endif
 }
+// wave-uniform bit mask of the lanes with pred (v_cmp into an SGPR pair); the value is pinned so the compare is issued HERE and a
+// later `if (mask)` is only s_cmp + s_cbranch
+STAR_DEV uint64_t wave_ballot(bool pred) {
+#ifdef STAR_HOSTEMU
+  return wave_any(pred) ? 1ull : 0ull;
+#else
+  uint64_t m = __ballot(pred ? 1 : 0);
+  asm volatile("" : "+s"(m));
+  return m;
+#endif
+}
 // compile-time scheduling hint (LLVM sched_group_barrier): emit `n` instructions of class `mask` next
 #ifdef STAR_HOSTEMU
 #define STAR_SCHED_GROUP(mask, n, id)
@@ -484,6 +531,14 @@ STAR_DEV bool wave_any(bool pred) {
 #else
 #define STAR_SCHED_GROUP(mask, n, id) __builtin_amdgcn_sched_group_barrier((mask), (n), (id))
 #define STAR_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+
+// move a value that only MFMAs read (A / B operand) into the accumulator half of the unified register file: MFMA operands are
+// read from AGPRs in place, and the architectural VGPRs stay free for what vector instructions touch (one-wave-per-SIMD kernels)
+#ifdef STAR_HOSTEMU
+#define STAR_AGPR_PIN(x)
+#else
+#define STAR_AGPR_PIN(x) asm volatile("" : "+a"(x))
 #endif
 
 STAR_DEV float wave_sum(float v) {

@@ -285,7 +285,7 @@ def ref_attention(q, k, v, heads):
     return o.transpose(1, 2).reshape(B, -1, heads * 64)
 
 
-@pytest.mark.parametrize("variant", [2, 4, 5, 6, 7, 8, 9, 10, 20, 21, 22, 23, 27, 30, 31, 32, 33])
+@pytest.mark.parametrize("variant", [9, 40, 41])
 @pytest.mark.parametrize("B,heads,Nq,Nk", [(2, 2, 300, 300), (1, 5, 80, 80), (3, 1, 257, 64), (1, 2, 64, 1), (9, 1, 33, 130), (1, 1, 130, 129)])
 def test_flash_attention_self(ctx, dtype, B, heads, Nq, Nk, variant):
     """spatial self-attention (unet_v2v.py:472 -> :184) on a fused QKV buffer, ragged q/k tails."""
@@ -329,7 +329,12 @@ def test_product_library_rejects_bench_variants(ctx, dtype):
     ctx.attention(q[..., :64], q[..., 64:128], q[..., 128:], 1, variant=0)   # 0 = default = the product kernel
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 15, 20, 21, 22, 23, 24, 27, 30, 31, 32, 33])
+# the measured-and-lost A/B kernels of rounds 1-2 (bench build / emulator only): one smoke case each -- they do not ship, their full
+# parity matrix ran in rounds 1-2 (profiles/r02_pytest_gpu_v1.txt)
+LOSING_VARIANTS = [0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 15, 20, 21, 22, 23, 24, 27, 30, 31, 32, 33]
+
+
+@pytest.mark.parametrize("variant", [9, 40, 41] + LOSING_VARIANTS)
 def test_flash_attention_variants_agree(ctx, dtype, variant):
     """all kernel variants (baseline / v2 / v3 with the augmented-k running max) against the fp32 reference, incl. a
     ragged key tail, strongly negative logits in tile 0 and a late spike that forces the rescale branch."""
@@ -348,7 +353,7 @@ def test_flash_attention_variants_agree(ctx, dtype, variant):
     assert_close(out, ref_attention(q, k, v, heads), dtype, scale=6.0, what=f"flash variant {variant}")
 
 
-@pytest.mark.parametrize("variant", [2, 6, 7, 8, 9, 10, 15, 20, 21, 22, 27, 30, 31, 32, 33])
+@pytest.mark.parametrize("variant", [9, 40, 41])
 def test_flash_attention_forced_rescale(ctx, dtype, variant):
     """a key spike late in the sequence forces the online-softmax rescale branch with a large max jump."""
     ctx = need_variant(ctx, variant == 9)
@@ -366,7 +371,7 @@ def test_flash_attention_forced_rescale(ctx, dtype, variant):
     assert_close(out, ref_attention(q, k, v, heads), dtype, what="flash rescale")
 
 
-@pytest.mark.parametrize("variant", [2, 6, 7, 8, 9, 10, 15, 20, 21, 22, 27, 30, 31, 32, 33])
+@pytest.mark.parametrize("variant", [9, 40, 41])
 def test_flash_attention_growing_max(ctx, dtype, variant):
     """scores that keep growing along the key axis (every tile moves the maximum by several binades, some by more than
     the fp16 exponent range) and a first tile far below everything that follows: the lazy-max variants must take their
@@ -385,6 +390,23 @@ def test_flash_attention_growing_max(ctx, dtype, variant):
     q, k, v = q.to(dtype), k.to(dtype), v.to(dtype)
     out = ctx.attention(dev(ctx, q), dev(ctx, k), dev(ctx, v), heads, variant=variant)
     assert_close(out, ref_attention(q, k, v, heads), dtype, scale=6.0, what=f"flash growing max v{variant}")
+
+
+@pytest.mark.parametrize("variant", [9, 40, 41])
+@pytest.mark.parametrize("Nq,Nk", [(150, 1100), (70, 1024), (390, 1217)])
+def test_flash_attention_long_key_range(ctx, dtype, variant, Nq, Nk):
+    """key ranges >= 1024 take the packed 16-bit row sums (f16) and, in the one-wave-per-SIMD kernels (40 / 41), many trips of the
+    query-block pipeline incl. odd / even tile counts, a ragged last tile and a late spike that moves the running maximum."""
+    ctx = need_variant(ctx, variant == 9)
+    g = torch.Generator().manual_seed(Nq * 7 + Nk)
+    q = torch.randn(1, Nq, 64, generator=g)
+    k = torch.randn(1, Nk, 64, generator=g)
+    v = torch.randn(1, Nk, 64, generator=g)
+    k[:, Nk - 100] = q[:, 3] * 3.0
+    k[:, 700] = q[:, Nq - 1] * 2.0
+    q, k, v = q.to(dtype), k.to(dtype), v.to(dtype)
+    out = ctx.attention(dev(ctx, q), dev(ctx, k), dev(ctx, v), 1, variant=variant)
+    assert_close(out, ref_attention(q, k, v, 1), dtype, what=f"flash long keys v{variant}")
 
 
 @pytest.mark.parametrize("Fr,HW,heads", [(5, 7, 2), (32, 9, 1), (40, 5, 2), (16, 130, 5), (1, 4, 1), (64, 3, 1), (80, 5, 2), (97, 3, 1), (128, 2, 1)])
