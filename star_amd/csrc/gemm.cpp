@@ -1,5 +1,6 @@
 // gemm.cpp -- argument checks and storage-type dispatch of the GEMM / implicit-conv operator (kernels: gemm.h; tile selection and
 // launch: gemm_impl.h, compiled per type in gemm_f16.cpp / gemm_bf16.cpp).
+#include <cstdlib>
 #include "ops.h"
 
 namespace star {
@@ -30,6 +31,14 @@ int op_gemm(Ctx* ctx, const GemmArgs& a) {
   ProfScope ps(ctx, a.mode == A_PLAIN ? PK_GEMM : (a.mode == A_TCONV3 ? PK_TCONV : PK_CONV), 2.0 * a.M * (double)a.N * a.K,
                ((double)a.M * (a.mode == A_PLAIN ? a.K : a.Cin) + (double)a.M * ((a.epi & EPI_GEGLU) ? a.N / 2 : a.N)) * 2.0,
                a.M, a.N, a.K, a.epi);
+  if (a.group_m < 0) {   // A/B aid: STAR_GEMM_GROUP_M overrides the automatic choice of the tile walk (gemm.h)
+    if (const char* e = std::getenv("STAR_GEMM_GROUP_M")) {
+      GemmArgs b = a;
+      b.group_m = std::atoi(e);
+      if (ctx->dtype == DT_F16) return launch_gemm_f16(ctx, b);
+      if (ctx->dtype == DT_BF16) return launch_gemm_bf16(ctx, b);
+    }
+  }
   if (ctx->dtype == DT_F16) return launch_gemm_f16(ctx, a);
   if (ctx->dtype == DT_BF16) return launch_gemm_bf16(ctx, a);
   return ctx->fail("gemm: unsupported dtype");

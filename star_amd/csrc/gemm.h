@@ -40,6 +40,7 @@ struct GemmParams {
   int up_crop;   // A_CONV3X3_UP: rows dropped at top and bottom of the 2x-upsampled image (1: UNet Upsample, 0: VAE Upsample2D)
   int epi;
   int tiles_m, tiles_n;
+  int group_m;   // > 1: the tile walk runs column-major inside groups of group_m tile rows (see the kernel)
   // EPI_ROWAFF (LayerNorm folded into this GEMM): out = a_m * acc + b_m * s_n + c_n with (a_m, b_m) = rowab[m], s_n = colsum[n],
   // c_n = bias[n]
   const float* rowab;   // [M][2]
@@ -107,7 +108,18 @@ gemm_kernel(const GemmParams p) {
     const int xcd = bid & 7, slot = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
   }
-  const int tile_m = bid / p.tiles_n, tile_n = bid % p.tiles_n;
+  // The 32 workgroups an XCD runs at a time are 32 CONSECUTIVE ids.  Row-major ids make them one row of tiles when tiles_n >= 32:
+  // one A panel and 32 W panels per K step (33 x 32 KB unique of the 64 requested: every second byte comes over the fabric, and
+  // the loop is paced by that, profiles/r03_lds_dma_bw_probe.txt).  Walking column-major inside groups of group_m tile rows makes
+  // them a group_m x (32 / group_m) block: 8 + 4 panels unique, the rest are L2 hits.
+  int tile_m = bid / p.tiles_n, tile_n = bid % p.tiles_n;
+  if (p.group_m > 1) {
+    const int per_group = p.group_m * p.tiles_n;
+    const int g = bid / per_group, in = bid - g * per_group;
+    const int rows = p.tiles_m - g * p.group_m < p.group_m ? p.tiles_m - g * p.group_m : p.group_m;
+    tile_m = g * p.group_m + in % rows;
+    tile_n = in / rows;
+  }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   if constexpr (!F32OUT) {   // this tile's bias slice, read from LDS in the epilogue (visible after the main loop's barriers)

@@ -21,6 +21,7 @@ static int launch_gemm_f(Ctx* ctx, const GemmArgs& a) {
   p.rowab = a.rowab; p.colsum = a.colsum;
   p.tiles_m = (a.M + BM - 1) / BM;
   p.tiles_n = (a.N + BN - 1) / BN;
+  p.group_m = a.group_m >= 0 ? a.group_m : (p.tiles_n >= 12 ? 8 : 1);   // auto: where a row of tiles is wide (measured +3-11 %, 8192^3 1140 -> 1233 TF/s; narrower rows lose 0-4 %: profiles/r03_gemm_group_ab.txt)
   // 2 stages x 64 k, or PIPE ring slots x 32 k; never less than the epilogue's per-wave staging blocks
   constexpr size_t smem_loop = PIPE ? (size_t)PIPE * (BM + BN) * 64 : 2 * (size_t)(BM + BN) * 128;
   constexpr size_t smem_epi = (size_t)WM * WN * 32 * (BN / WN * 2 + 8);

@@ -30,6 +30,7 @@ struct GemmArgs {
   int epi = 0;
   int force_tile = 0;  // 0 = auto; 1 = 256x256, 2 = 256x320, 3 = 128x128, 4 = 256x128 (tests)
   const float* rowab = nullptr; const float* colsum = nullptr;   // EPI_ROWAFF operands
+  int group_m = -1;    // tile walk: -1 auto, 0 / 1 row-major, n column-major inside groups of n tile rows (gemm.h)
   int persist = 0;     // > 0: at most this many workgroups walk the output tiles (multiple of 8); 0 = one workgroup per tile
 };
 int op_gemm(Ctx* ctx, const GemmArgs& a);
