@@ -1,0 +1,82 @@
+"""What "within fp16 tolerance" means, measured on the reference itself (TEST INFRASTRUCTURE ONLY; needs /root/reference).
+
+    python oracle/make_golden_fp16ref.py        # ~1 min
+
+BASELINE.json's parity bar is stated against the reference CPU path (fp32) "within a stated fp16 tolerance"; the reference's own
+GPU arithmetic is `generator.half()` under autocast (video_to_video_model.py:42,98).  This script runs the REFERENCE's UNet and
+the REFERENCE's sampler twice on the CPU on identical inputs / weights / injected noise -- once in fp32, once with half weights
+under torch.autocast(float16) -- and stores both final latents.  tests/test_pipeline.py then asserts that the HIP fp16 path is at
+least as close to the fp32 result as the reference's own fp16 arithmetic is (plus the absolute 50 dB bar).
+Reduced width (SMALL_TEST_CONFIG) so that the CPU half-precision kernels finish in a minute; 6 frames, latent 18x16, 3 solver
+steps = 6 denoiser forwards with CFG 7.5 and rescale 0.2.
+"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import ref_loader  # noqa: E402
+from make_golden import build_reference_unet  # noqa: E402
+from star_amd.topology import SMALL_TEST_CONFIG, random_state_dict  # noqa: E402
+
+CFG16 = dict(frames=6, latent=(18, 16), steps=3, seed=21, noise_seed=5, wseed=0)
+
+
+def fp16ref_inputs():
+    cfg = SMALL_TEST_CONFIG
+    g = torch.Generator().manual_seed(CFG16["seed"])
+    F_, (h, w) = CFG16["frames"], CFG16["latent"]
+    noise = torch.randn(1, 4, F_, h, w, generator=g)
+    hint = torch.randn(1, 4, F_, h, w, generator=g) * 0.5
+    y = torch.randn(1, 77, cfg.context_dim, generator=g)
+    neg = torch.randn(1, 77, cfg.context_dim, generator=g)
+    return noise, hint, y, neg
+
+
+def main():
+    torch.set_grad_enabled(False)
+    cfg = SMALL_TEST_CONFIG
+    dif, sol, sch = ref_loader.load_diffusion_modules()
+    sd = random_state_dict(cfg, seed=CFG16["wseed"])
+    noise, hint, y, neg = fp16ref_inputs()
+    gd = dif.GaussianDiffusion(sigmas=sch.noise_schedule(schedule="logsnr_cosine_interp", n=1000, zero_terminal_snr=True, scale_min=2.0, scale_max=4.0))
+
+    def run(half):
+        net = build_reference_unet(cfg).eval()
+        net.load_state_dict(sd, strict=True)
+        if half:
+            net = net.half()
+        gen = torch.Generator().manual_seed(CFG16["noise_seed"])
+
+        class InjectedNoise:
+            def __init__(self, x, smin, smax, seed=None, transform=None):
+                self.shape = x.shape
+
+            def __call__(self, s, s_next):
+                return torch.randn(self.shape, generator=gen)
+
+        sol.BrownianTreeNoiseSampler = InjectedNoise
+
+        def model(x, t=None, y=None, hint=None, hint_chunk=None, variant_info=None):
+            if half:   # what VideoToVideo_sr.test() does on the GPU: half module, autocast region (video_to_video_model.py:42,98)
+                with torch.autocast("cpu", dtype=torch.float16):
+                    return net(x, t=t, y=y, hint=hint, hint_chunk=hint_chunk, variant_info=variant_info)
+            return net(x, t=t, y=y, hint=hint, hint_chunk=hint_chunk, variant_info=variant_info)
+
+        return gd.sample_sr(noise=noise, model=model, model_kwargs=[{"y": y}, {"y": neg}, {"hint": hint}], guide_scale=7.5, guide_rescale=0.2,
+                            solver="dpmpp_2m_sde", solver_mode="normal", steps=CFG16["steps"], t_max=899, t_min=0, discretization="trailing",
+                            chunk_inds=None).float()
+
+    x32 = run(False)
+    x16 = run(True)
+    d = (x16 - x32).double()
+    rel = float(d.pow(2).mean().sqrt() / x32.double().pow(2).mean().sqrt())
+    print(f"reference fp16 (half + autocast) vs reference fp32, final latent: rel rms {rel:.3e}, range [{float(x32.min()):.2f}, {float(x32.max()):.2f}]")
+    torch.save({"cfg": CFG16, "x0_fp32": x32.clone(), "x0_ref_fp16": x16.clone()}, os.path.join(ROOT, "tests", "golden", "fp16ref_small.pt"))
+
+
+if __name__ == "__main__":
+    main()

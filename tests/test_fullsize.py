@@ -69,6 +69,54 @@ def test_spatial_attention_full_length_peaked_logits(dtype):
 
 
 @pytest.mark.gpu
+def test_spatial_attention_cfg4_length_vs_fp32():
+    """BASELINE config[3] (32 f 540x960 -> x4, latent 274 x 488): one (frame, head) of the L0 spatial self-attention at its real
+    length N = 133712 (2090 key tiles, ragged tail of 16) against fp32 softmax(QK^T/8)V taken 2048 query rows at a time."""
+    from util import make_ctx
+    ctx = make_ctx("hip", torch.float16, None)
+    dev = ctx.torch_device
+    g = torch.Generator().manual_seed(4)
+    N = 274 * 488
+    qkv = (torch.randn(1, N, 192, generator=g) * 1.5).to(torch.float16).to(dev)
+    qkv[0, N - 500, 64:128] = qkv[0, 77, :64] * 2.5                                   # a late key that moves one row's maximum
+    out = ctx.attention(qkv[..., :64], qkv[..., 64:128], qkv[..., 128:], 1).float()[0]
+    q, k, v = (qkv[0, :, i * 64:(i + 1) * 64].float() for i in range(3))
+    ref = torch.empty_like(out)
+    for s0 in range(0, N, 2048):
+        ref[s0:s0 + 2048] = torch.softmax(q[s0:s0 + 2048] @ k.T / 8.0, dim=-1) @ v
+    err = float((out - ref).abs().max())
+    rel = float((out - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+    print(f"spatial attention at N = {N}: max abs err {err:.2e}, relative rms {rel:.2e}")
+    assert torch.isfinite(out).all() and err <= 4e-3 * max(1.0, float(ref.abs().max())) and rel <= 2e-3, (err, rel)
+    ctx.sync()
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_vae_mid_attention_at_its_real_block_size(monkeypatch):
+    """the single-head d = 512 mid-block attention of the VAE sends its fp32 logits through HBM in blocks of query rows bounded
+    by 2 GiB of scratch (vae.cpp).  Full-width encoder on one cfg2 frame (976 x 1728 -> 26352 tokens): the natural 2 GiB blocks
+    (2 of them) against the whole matrix at once -- bit-identical; on one cfg4 frame (2192 x 3904 -> 133712 tokens, 53 natural
+    blocks) against 5120-row blocks -- bit-identical and finite."""
+    from star_amd.vae import AutoencoderKLTemporalDecoder
+    from star_amd.vae_topology import VaeConfig, random_vae_state_dict
+    cfg = VaeConfig()
+    vae = AutoencoderKLTemporalDecoder(cfg, dtype=torch.float16).load_state_dict(random_vae_state_dict(cfg, seed=2))
+    g = torch.Generator().manual_seed(5)
+    for (H, W, other_rows) in ((976, 1728, 26368), (2192, 3904, 5120)):
+        x = (torch.randn(1, 3, H // 8, W // 8, generator=g) * 0.5).clamp(-1, 1)
+        x = torch.nn.functional.interpolate(x, size=(H, W), mode="bilinear").cuda()
+        monkeypatch.delenv("STAR_VAE_ATTN_ROWS", raising=False)
+        natural = vae.encode(x).latent_dist.parameters.float().cpu()
+        monkeypatch.setenv("STAR_VAE_ATTN_ROWS", str(other_rows))
+        other = vae.encode(x).latent_dist.parameters.float().cpu()
+        assert natural.shape == (1, 8, H // 8, W // 8) and torch.isfinite(natural).all()
+        assert torch.equal(natural, other), (H, W, float((natural - other).abs().max()))
+    monkeypatch.delenv("STAR_VAE_ATTN_ROWS", raising=False)
+    vae.ctx.sync()
+
+
+@pytest.mark.gpu
 def test_full_model_forward_pair_at_cfg2_size():
     """the whole denoiser at cfg2 size: finite, the shared-prefix CFG pair is bit-identical to two plain forwards, and the
     two text contexts give different predictions."""

@@ -14,8 +14,15 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from util import fmt_metrics, frames_u8, parity_metrics  # noqa: E402
 GOLD = os.path.join(ROOT, "tests", "golden", "cfg1_full.pt")
 torch.set_grad_enabled(False)
+# PSNR convention (stated next to every number, round-2 review): the asserted 50 dB bar uses peak = max - min of the reference
+# tensor -- latents have no nominal range, and random-init weights decode to frames spanning [-3, 3.4] instead of [-1, 1].  The
+# figure at the nominal peak 2.0, the range-free relative rms and (for frames) the PSNR of the clamped 8-bit frames are printed
+# and bounded as well.  For scale: the REFERENCE's own fp16 arithmetic (half + autocast) differs from its fp32 arithmetic by a
+# relative rms of 1.5e-2 after 6 forwards (tests/golden/fp16ref_small.pt, asserted in tests/test_pipeline.py).
 
 
 def psnr(a, b, data_range):
@@ -70,16 +77,17 @@ def test_denoiser_on_identical_latents_matches_the_reference(pipeline):
     kw = [{"y": y.to(dev)}, {"y": neg.to(dev)}, {"hint": z}]
     t = torch.LongTensor([CFG1["total_noise_levels"] - 1]).to(dev)
     first = model.diffusion.denoise_x0(noised, t, model.generator, kw, CFG1["guide_scale"], 0.2).cpu()
-    rng1 = float(gold["x0_first"].max() - gold["x0_first"].min())
-    p1 = psnr(first, gold["x0_first"], rng1)
+    m1 = parity_metrics(first, gold["x0_first"])
+    p1 = m1["psnr_range"]
     x0 = model.diffusion.sample_sr(noise=noised, model=model.generator, model_kwargs=kw, guide_scale=CFG1["guide_scale"], guide_rescale=0.2,
                                    solver="dpmpp_2m_sde", solver_mode=CFG1["solver_mode"], steps=CFG1["steps"], t_max=CFG1["total_noise_levels"] - 1,
                                    t_min=0, discretization="trailing", chunk_inds=None, noise_sampler_cls=Sampler).cpu()
-    rng = float(gold["x0_final"].max() - gold["x0_final"].min())
-    p = psnr(x0, gold["x0_final"], rng)
-    print(f"cfg1 full width, fp16: first-evaluation x0 PSNR {p1:.1f} dB, final latent PSNR {p:.1f} dB (ranges {rng1:.2f} / {rng:.2f})")
+    m = parity_metrics(x0, gold["x0_final"])
+    p = m["psnr_range"]
+    print(f"cfg1 full width, fp16: first-evaluation x0 {fmt_metrics(m1)}; final latent after 10 forwards {fmt_metrics(m)}")
     assert torch.isfinite(x0).all()
     assert p1 >= 50.0 and p >= 50.0, (p1, p)
+    assert m1["rel_rms"] <= 1.2e-2 and m["rel_rms"] <= 2e-2, (m1, m)   # measured on MI355X: 8.0e-3 / 1.28e-2
 
 
 @pytest.mark.gpu
@@ -94,10 +102,9 @@ def test_vae_encode_16_bit_storage_vs_the_fp32_encode_of_the_reference_path(pipe
     padded = model.generator.ctx.resize_pad(video.to(dev, torch.float32), (th, tw), pad_to_fit(th, tw), 1.0).unsqueeze(0)
     model.rng.manual_seed(CFG1["rng_seed"])
     z = model.vae_encode(padded).cpu()
-    rng = float(gold["z"].max() - gold["z"].min())
-    p = psnr(z, gold["z"], rng)
-    print(f"cfg1 VAE encode, 16-bit activations vs fp32 CPU encode: latent PSNR {p:.1f} dB (range {rng:.2f})")
-    assert p >= 60.0, p
+    m = parity_metrics(z, gold["z"])
+    print(f"cfg1 VAE encode, 16-bit activations vs fp32 CPU encode: latent {fmt_metrics(m)}")
+    assert m["psnr_range"] >= 60.0 and m["rel_rms"] <= 1e-3, m
 
 
 @pytest.mark.gpu
@@ -111,7 +118,12 @@ def test_whole_test_call_psnr_at_least_50_db(pipeline):
                      guide_scale=CFG1["guide_scale"], max_chunk_len=32)
     ref = gold["video_out_f16"].float()
     assert out.shape == ref.shape and out.dtype == torch.float32 and out.device.type == "cpu"
-    lo, hi = gold["out_range"]
-    p = psnr(out, ref, hi - lo)
-    print(f"cfg1 full width, fp16: decoded-output PSNR vs the reference CPU path {p:.1f} dB (range [{lo:.2f}, {hi:.2f}])")
-    assert torch.isfinite(out).all() and p >= 50.0, p
+    m = parity_metrics(out, ref, nominal_peak=2.0)
+    u8o, u8r = frames_u8(out), frames_u8(ref)
+    p8 = 10 * math.log10(255.0 ** 2 / max(float((u8o - u8r).pow(2).mean()), 1e-30))
+    print(f"cfg1 full width, fp16: decoded frames vs the reference CPU path {fmt_metrics(m)}; clamped 8-bit frames (what save_video "
+          f"writes) {p8:.1f} dB at peak 255, {float((u8o != u8r).float().mean()) * 100:.1f} % of the bytes differ (by at most {int((u8o - u8r).abs().max())})")
+    assert torch.isfinite(out).all() and m["psnr_range"] >= 50.0, m
+    # the same error at the nominal [-1, 1] peak and on the 8-bit frames: bounded, not at 50 dB -- nor is the reference's own
+    # fp16 path (tests/test_pipeline.py::test_hip_fp16_is_as_close_to_fp32_as_the_references_own_fp16)
+    assert m["psnr_nominal"] >= 46.0 and p8 >= 46.0 and m["rel_rms"] <= 1.5e-2, (m, p8)

@@ -30,3 +30,31 @@ def assert_close(out, ref, dtype, scale=4.0, what=""):
     err = float((out - ref).abs().max())
     assert err <= tol, f"{what}: max abs err {err:.4g} > tol {tol:.4g}"
     return err
+
+
+def parity_metrics(out, ref, nominal_peak=None):
+    """The figures every PSNR-type parity test prints and asserts on (round-2 review: the peak of a PSNR is a free parameter, so
+    state it).  `range`: peak = max - min of the reference tensor (what the tests of rounds 1-2 used; the only meaningful peak for
+    latents and for random-init weights, whose decoded frames span [-3, 3.4] instead of [-1, 1]).  `nominal`: peak = nominal_peak
+    (2.0 for frames that nominally live in [-1, 1]).  `rel_rms`: range-free, ||out - ref|| / ||ref||."""
+    import math
+    o, r = out.detach().double().cpu(), ref.detach().double().cpu()
+    mse = float((o - r).pow(2).mean())
+    rng = float(r.max() - r.min())
+    m = {"rel_rms": math.sqrt(mse) / max(float(r.pow(2).mean().sqrt()), 1e-30), "range": rng,
+         "psnr_range": 10 * math.log10(rng ** 2 / max(mse, 1e-30))}
+    if nominal_peak is not None:
+        m["psnr_nominal"] = 10 * math.log10(nominal_peak ** 2 / max(mse, 1e-30))
+    return m
+
+
+def fmt_metrics(m):
+    s = f"PSNR {m['psnr_range']:.1f} dB at peak = range {m['range']:.2f}"
+    if "psnr_nominal" in m:
+        s += f", {m['psnr_nominal']:.1f} dB at the nominal peak 2.0"
+    return s + f", relative rms {m['rel_rms']:.2e}"
+
+
+def frames_u8(x):
+    """what save_video writes: tensor2vid's [-1, 1] -> [0, 255] map, clamped and rounded (inference_utils.py:16-23)"""
+    return ((x.detach().float().cpu() + 1.0) * 127.5).clamp(0, 255).round()
