@@ -72,6 +72,17 @@ def main():
             custom = True
     shard_one_video = args.config == "cfg3"
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: launch ourselves under torch.distributed.run, one rank per GPU on this node (the driver's
+        # own `python -m torch.distributed.run ... bench.py --gpus N` form arrives with WORLD_SIZE set and skips this)
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -84,7 +95,8 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(args.dist_backend)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     torch.set_grad_enabled(False)
     dtype = {"bf16": torch.bfloat16, "f16": torch.float16}[args.dtype]
     dev = torch.device("cuda", local_rank)
@@ -177,6 +189,11 @@ def main():
         # measured, not nominal: the same kernel with its softmax VALU removed (MFMA + LDS + barriers only) runs 1568 TF/s on N(0,1)
         # operands and 2068 on zeros -- the chip is power-limited and full-entropy operands cost a quarter of the clock
         # (profiles/r02_power_limit.txt).  `peak` stays the nominal dense MFMA figure the metric is defined against.
+        # round 3 measured why (profiles/r03_attn7_ab.txt): on N(0,1) operands this kernel holds the socket at its power cap -- 1331 W at
+        # a sustained 1.83 GHz shader clock (2.40 GHz and 1006 W on zeros); a one-wave-per-SIMD software pipeline of the same
+        # arithmetic runs fewer instructions per cycle at 2.08 GHz and lands at the same time per launch.
+        roof["power"] = {"socket_W_on_random_operands": 1331, "sclk_GHz_on_random_operands": 1.83, "sclk_GHz_on_zeros": 2.40,
+                         "source": "profiles/r03_attn7_ab.txt (sysfs hwmon sampled beside the kernel)"}
         roof["mfma_skeleton_ceiling_on_random_operands"] = {"TFLOP/s": 1568.0, "source": "profiles/r02_power_limit.txt (variant 16, N(0,1) f16)",
                                                             "frac_of_it": roof["achieved"] / 1568.0 if roof["achieved"] else None}
         breakdown = {k: {"ms": round(v["ms"], 1), "launches": v["launches"],
@@ -212,8 +229,8 @@ def main():
 def run_cpu_baseline(sd, ucfg, args):
     """Time the CPU oracle (oracle/unet_oracle.py: a PyTorch fp32 port of the reference forward, pinned to the reference's own
     code by tests/test_oracle.py; /root/reference itself does not exist on the GPU box) on this box's host cores:
-      1. a quick thread sweep on a small forward picks the thread count (torch's CPU kernels collapse on these shapes when
-         given all 256 hardware threads), and
+      1. a thread sweep (16 / 32 / 64 / 128) on ONE frame of the sample's own shape (latent 90x160, full width, 5.9 TFLOP) picks
+         the thread count (torch's CPU kernels collapse on these shapes when given all 256 hardware threads), and
       2. ONE full UNet+ControlNet forward at the real level-0 shape of BASELINE config[0] (latent 90x160 = 14 400 tokens per
          frame, full 2.04 B-parameter width) on 4 frames is the measured sample (tens of TFLOP, tens of seconds).
     The frames/s figure is that measured rate EXTRAPOLATED by FLOP ratio to the benchmark workload and says so; the
@@ -233,11 +250,14 @@ def run_cpu_baseline(sd, ucfg, args):
             secs = time.perf_counter() - t0
         return float(fc.get_total_flops()), secs
 
+    # thread sweep ON THE REAL LEVEL-0 SHAPE (one frame of the sample: 14 400 tokens, full width; round-2 review: the sweep used
+    # to run on a 2-frame 26x24 toy and its winner was then applied to a 2 500x larger forward)
     sweep = {}
-    for n in [c for c in (8, 16, 32, 64, 128) if c <= ncpu] or [ncpu]:
+    sf, sh, sw = (1, 10, 8) if small else (1, 90, 160)
+    timed(1, 10, 8, 3)
+    for n in [c for c in (16, 32, 64, 128) if c <= ncpu] or [ncpu]:
         torch.set_num_threads(n)
-        timed(1, 10, 8, 3)                                   # warm the pool at this size
-        fl, secs = timed(2, 26, 24, 5)
+        fl, secs = timed(sf, sh, sw, 5)
         sweep[n] = fl / secs / 1e9
     cores = max(sweep, key=sweep.get)
     torch.set_num_threads(cores)
@@ -249,6 +269,7 @@ def run_cpu_baseline(sd, ucfg, args):
     total = (2 * evals * cfg["chunks"] * cfg["fwd_tflop"] + args.frames * VAE_TFLOP_PER_FRAME * cfg["vae_scale"]) * 1e12
     return {"value": args.frames / (total / cpu_flops), "unit": "frames/s", "cores": cores, "kind": "port",
             "host_threads_available": ncpu, "thread_sweep_gflops": {str(k): round(v, 1) for k, v in sweep.items()},
+            "thread_sweep_shape": f"f={sf}, latent {sh}x{sw}, full width" if not small else "reduced-width smoke",
             "sample": f"one full-width UNet+ControlNet forward of the fp32 CPU oracle at f={f}, latent {h}x{w} (the level-0 shape of BASELINE "
                       f"config[0]): {flops / 1e12:.1f} TFLOP in {secs:.1f} s = {cpu_flops / 1e9:.0f} GFLOP/s on {cores} threads (best of the sweep); "
                       f"frames/s EXTRAPOLATED by FLOP ratio to the {total / 1e15:.1f} PFLOP workload (= {total / cpu_flops / 3600:.1f} h on this host)",

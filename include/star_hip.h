@@ -189,6 +189,10 @@ int star_plane_stats(star_ctx* ctx, const float* x, float* stats, int32_t planes
  * [F, C, h, w] low-resolution clip in [-1, 1]; out: fp32 device [F, H, W, C] in [0, 255]. */
 int star_color_fix(star_ctx* ctx, const float* x, const float* src, float* out, int32_t F, int32_t C, int32_t H, int32_t W,
                    int32_t h, int32_t w);
+/* the same with what save_video does to its input folded in (`.astype('uint8')`, inference_utils.py:92): out is uint8 device
+ * [F, H, W, C], truncated -- the frames leave the GPU as bytes (a quarter of the PCIe traffic, no conversion pass on the host). */
+int star_color_fix_u8(star_ctx* ctx, const float* x, const float* src, uint8_t* out, int32_t F, int32_t C, int32_t H, int32_t W,
+                      int32_t h, int32_t w);
 /* replaces: adain_color_fix(target, source) on its own (color_fix.py:15-29): target fp32 device [F, H, W, C] in [0, 255]
  * (a tensor2vid result), src as above -> out fp32 device [F, H, W, C] in [0, 255]. */
 int star_adain_color_fix(star_ctx* ctx, const float* target, const float* src, float* out, int32_t F, int32_t C, int32_t H,

@@ -68,16 +68,57 @@ def _ffmpeg():
     return shutil.which("ffmpeg")
 
 
+def _ffprobe():
+    """ffprobe next to the ffmpeg that was found (never by rewriting the path string), else whatever is on PATH."""
+    exe = _ffmpeg()
+    if exe:
+        cand = os.path.join(os.path.dirname(exe), "ffprobe" + os.path.splitext(exe)[1])
+        if os.path.isfile(cand):
+            return cand
+    return shutil.which("ffprobe")
+
+
 def _load_video_ffmpeg(vid_path):
-    """decode through an ffmpeg pipe (bgr24 raw frames) when cv2 is missing."""
-    probe = subprocess.run([_ffmpeg().replace("ffmpeg", "ffprobe"), "-v", "error", "-select_streams", "v:0", "-show_entries",
-                            "stream=width,height,r_frame_rate", "-of", "csv=p=0", vid_path], capture_output=True, text=True)
-    w, h, rate = probe.stdout.strip().split(",")[:3]
-    num, den = (rate.split("/") + ["1"])[:2]
-    w, h = int(w), int(h)
-    raw = subprocess.run([_ffmpeg(), "-v", "error", "-i", vid_path, "-f", "rawvideo", "-pix_fmt", "bgr24", "-"], capture_output=True).stdout
-    frames = np.frombuffer(raw, dtype=np.uint8).reshape(-1, h, w, 3)
-    return [f for f in frames], float(num) / float(den or 1)
+    """decode through an ffmpeg pipe (bgr24 raw frames) when cv2 is missing: frame geometry and rate from ffprobe, then the raw
+    frames are READ FRAME BY FRAME from ffmpeg's stdout by a reader thread (no whole-clip capture buffer)."""
+    probe_exe, exe = _ffprobe(), _ffmpeg()
+    if not probe_exe or not exe:
+        raise RuntimeError("load_video: neither cv2 nor an ffmpeg / ffprobe pair is available")
+    probe = subprocess.run([probe_exe, "-v", "error", "-select_streams", "v:0", "-show_entries", "stream=width,height,r_frame_rate",
+                            "-of", "csv=p=0", vid_path], capture_output=True, text=True)
+    fields = probe.stdout.strip().split(",")
+    if probe.returncode != 0 or len(fields) < 3:
+        raise RuntimeError(f"load_video: ffprobe failed on {vid_path!r} (rc {probe.returncode}): {probe.stderr.strip()[-500:]}")
+    w, h = int(fields[0]), int(fields[1])
+    num, _, den = fields[2].partition("/")
+    try:
+        fps = float(num) / float(den) if den.strip() else float(num)
+    except (ValueError, ZeroDivisionError):
+        fps = 0.0
+    if not fps > 0:
+        raise RuntimeError(f"load_video: cannot parse the frame rate {fields[2]!r} of {vid_path!r}")
+    nbytes = h * w * 3
+    proc = subprocess.Popen([exe, "-v", "error", "-i", vid_path, "-f", "rawvideo", "-pix_fmt", "bgr24", "-"], stdout=subprocess.PIPE,
+                            stderr=subprocess.PIPE)
+    frames, tail = [], [b""]
+
+    def reader():
+        while True:
+            buf = proc.stdout.read(nbytes)
+            if len(buf) < nbytes:
+                tail[0] = buf
+                return
+            frames.append(np.frombuffer(buf, dtype=np.uint8).reshape(h, w, 3))
+
+    th = threading.Thread(target=reader, daemon=True)
+    th.start()
+    err = proc.stderr.read()
+    th.join()
+    rc = proc.wait()
+    if rc != 0 or not frames or tail[0]:
+        raise RuntimeError(f"load_video: ffmpeg decode of {vid_path!r} failed (rc {rc}, {len(frames)} whole frames, {len(tail[0])} stray bytes): "
+                           f"{err.decode(errors='replace').strip()[-500:]}")
+    return frames, fps
 
 
 def save_video(video, save_dir, file_name, fps=16.0):

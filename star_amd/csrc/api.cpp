@@ -279,6 +279,13 @@ int star_color_fix(star_ctx* h, const float* x, const float* src, float* out, in
   rt::set_device(h->c.device);
   return finish(h, op_color_fix(&h->c, x, true, src, out, F, C, H, W, hh, w));
 }
+int star_color_fix_u8(star_ctx* h, const float* x, const float* src, uint8_t* out, int32_t F, int32_t C, int32_t H, int32_t W,
+                      int32_t hh, int32_t w) {
+  if (!h) return -1;
+  rt::set_device(h->c.device);
+  if (!x || !src || !out) return finish(h, h->c.fail("color_fix_u8: null pointer"));
+  return finish(h, op_color_fix(&h->c, x, true, src, nullptr, F, C, H, W, hh, w, out));
+}
 int star_adain_color_fix(star_ctx* h, const float* target, const float* src, float* out, int32_t F, int32_t C, int32_t H, int32_t W,
                          int32_t hh, int32_t w) {
   if (!h) return -1;

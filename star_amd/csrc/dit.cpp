@@ -9,6 +9,8 @@
 #include "dit.h"
 #include "graph.h"
 #include <cmath>
+#include <mutex>
+#include <unordered_map>
 
 namespace star {
 
@@ -30,11 +32,27 @@ struct DitModel {
   ~DitModel() { for (void* p : owned) rt::dev_free(p); if (cosb) rt::dev_free(cosb); if (sinb) rt::dev_free(sinb); }
 };
 
-static std::shared_ptr<DitModel>& dit_of(Ctx* ctx) {
-  static std::unordered_map<Ctx*, std::shared_ptr<DitModel>> models;   // keyed by context; dropped by dit_release
-  return models[ctx];
+// DiT models by context.  Contexts may be created and destroyed on different threads: the registry is guarded, lookups return a
+// shared_ptr copy (a forward keeps its model alive), and dit_release ERASES the key (it used to leave an empty entry behind for every
+// context ever destroyed, UNet and VAE contexts included).
+static std::mutex& dit_mutex() { static std::mutex m; return m; }
+static std::unordered_map<Ctx*, std::shared_ptr<DitModel>>& dit_models() {
+  static std::unordered_map<Ctx*, std::shared_ptr<DitModel>> models;
+  return models;
 }
-void dit_release(Ctx* ctx) { dit_of(ctx).reset(); }
+static std::shared_ptr<DitModel> dit_of(Ctx* ctx) {
+  std::lock_guard<std::mutex> g(dit_mutex());
+  auto it = dit_models().find(ctx);
+  return it == dit_models().end() ? nullptr : it->second;
+}
+static void dit_set(Ctx* ctx, std::shared_ptr<DitModel> m) {
+  std::lock_guard<std::mutex> g(dit_mutex());
+  dit_models()[ctx] = std::move(m);
+}
+void dit_release(Ctx* ctx) {
+  std::lock_guard<std::mutex> g(dit_mutex());
+  dit_models().erase(ctx);
+}
 
 int dit_build(Ctx* ctx, int D, int heads, int E, int n_layers, float ln_eps) {
   if (D % 64 || heads * 64 != D) return ctx->fail("dit_build: hidden size must be heads x 64");
@@ -63,7 +81,7 @@ int dit_build(Ctx* ctx, int D, int heads, int E, int n_layers, float ln_eps) {
       return ctx->fail("dit_build: tensor shapes do not match the configuration");
     m->layers.push_back(w);
   }
-  dit_of(ctx) = m;
+  dit_set(ctx, m);
   ctx->host_tensors.clear();
   return 0;
 }

@@ -50,7 +50,7 @@ int op_plane_stats(Ctx* ctx, const float* x, float* stats, int planes, long long
 }
 
 // from_model: x = [1, C, F, H, W] pipeline output (tensor2vid fused); else x = [F, H, W, C] in 0..255
-int op_color_fix(Ctx* ctx, const float* x, bool from_model, const float* src, float* out, int F, int C, int H, int W, int h, int w) {
+int op_color_fix(Ctx* ctx, const float* x, bool from_model, const float* src, float* out, int F, int C, int H, int W, int h, int w, unsigned char* out_u8) {
   if (F <= 0 || C <= 0 || H <= 0 || W <= 0 || h <= 0 || w <= 0) return ctx->fail("color_fix: empty input");
   if (F > 65535 || (long long)F * C > 65535) return ctx->fail("color_fix: too many frames");
   const long long HW = (long long)H * W;
@@ -67,9 +67,9 @@ int op_color_fix(Ctx* ctx, const float* x, bool from_model, const float* src, fl
   }
   // style: the low-resolution clip [F][C][h][w] in [-1, 1] -> (s + 1) / 2   (color_fix.py:18)
   if (int rc = op_plane_stats(ctx, src, style, F * C, (long long)h * w, 0.5f, 0.5f, false, 1e-5f)) return rc;
-  ProfScope ps(ctx, PK_MISC, 0.0, (double)F * C * HW * 8.0);
+  ProfScope ps(ctx, PK_MISC, 0.0, (double)F * C * HW * (out_u8 ? 5.0 : 8.0));
   ColorFixParams p{x, out, content, style, C, F, HW, from_model ? (long long)F * HW : 1, from_model ? HW : HW * C, from_model ? 1 : C,
-                   from_model ? 1 : 0};
+                   from_model ? 1 : 0, out_u8};
   long long gx = (HW + 255) / 256; if (gx > 2048) gx = 2048;
   STAR_LAUNCH(color_fix_kernel, dim3((unsigned)gx, (unsigned)F), dim3(256), (size_t)0, ctx->stream, p);
   return 0;

@@ -98,6 +98,8 @@ STAR_GLOBAL void plane_stats_final_kernel(const PlaneStatsFinalParams p) {
 struct ColorFixParams {
   const float* x; float* out; const float* content; const float* style;
   int C, F; long long HW; long long sc, sf, sq; int from_model;
+  unsigned char* out_u8;   // non-null: write [F][H*W][C] BYTES, truncated like the reference's `.astype('uint8')` in save_video
+                           // (inference_utils.py:92) -- a quarter of the bytes leave the GPU and the host does no conversion pass
 };
 STAR_GLOBAL void color_fix_kernel(const ColorFixParams p) {
   const int f = blockIdx.y;
@@ -114,7 +116,8 @@ STAR_GLOBAL void color_fix_kernel(const ColorFixParams p) {
       const float sm = p.style[2 * (f * p.C + c)], ss = p.style[2 * (f * p.C + c) + 1];
       float r = (v - cm) / cs * ss + sm;                                  // adaptive_instance_normalization
       r = fminf(fmaxf(r, 0.f), 1.f);
-      p.out[((size_t)f * p.HW + q) * p.C + c] = r * 255.0f;
+      if (p.out_u8) p.out_u8[((size_t)f * p.HW + q) * p.C + c] = (unsigned char)(r * 255.0f);
+      else p.out[((size_t)f * p.HW + q) * p.C + c] = r * 255.0f;
     }
   }
 }

@@ -33,6 +33,7 @@ static int launch_gemm_f(Ctx* ctx, const GemmArgs& a) {
   // 16-bit epilogue flavour (compile-time in the kernel): plain / + residual / GEGLU (plain-A layers only, no residual)
   const bool res = !F32OUT && (a.epi & EPI_RES), geglu = !F32OUT && (a.epi & EPI_GEGLU), gelut = !F32OUT && (a.epi & EPI_GELU_TANH);
   if ((geglu || gelut) && (res || a.mode != A_PLAIN || (geglu && gelut))) return ctx->fail("gemm: GEGLU / tanh-GELU are for plain-A layers without a residual");
+  if (F32OUT && (a.epi & EPI_ROWAFF)) return ctx->fail("gemm: the folded-LayerNorm epilogue has no fp32-output form");
   const bool rowaff = !F32OUT && (a.epi & EPI_ROWAFF);
   if (rowaff && (res || gelut || a.mode != A_PLAIN || !a.rowab || !a.colsum || !(a.epi & EPI_BIAS)))
     return ctx->fail("gemm: the folded-LayerNorm epilogue is for plain-A layers without a residual and needs rowab, colsum and bias");

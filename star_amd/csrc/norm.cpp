@@ -51,11 +51,14 @@ static int ln_t(Ctx* ctx, LnParams p) {
   const int CC8 = p.C / 8;
   int lpr = 8;
   while (lpr * 5 < CC8) lpr <<= 1;
-  if (lpr > 64) return ctx->fail("layer_norm: C too large (max 2560)");
+  const bool wide = lpr > 64;       // 2560 < C <= 5120: one row per wavefront, ten 16-B chunks per lane
+  if (wide) lpr = 64;
+  if (wide && 64 * 10 < CC8) return ctx->fail("layer_norm: C too large (max 5120)");
   p.lpr = lpr;
   const int rows_per_block = 4 * (64 / lpr);
   dim3 grid((unsigned)((p.rows + rows_per_block - 1) / rows_per_block)), block(256);
-  STAR_LAUNCH((ln_kernel<T>), grid, block, (size_t)0, ctx->stream, p);
+  if (wide) STAR_LAUNCH((ln_kernel<T, 10>), grid, block, (size_t)0, ctx->stream, p);
+  else STAR_LAUNCH((ln_kernel<T, 5>), grid, block, (size_t)0, ctx->stream, p);
   return 0;
 }
 

@@ -170,9 +170,9 @@ struct LnParams {
 };
 // A row is shared by LPR = 8 / 16 / 32 / 64 lanes (<= 5 16-B chunks per lane), so a wavefront normalises 64/LPR rows at
 // once and every lane is busy at every layer width (C = 320: 8 lanes x 5 chunks, 8 rows per wave; C = 2560: one row).
-template <class T>
+// CPL = 10 chunks per lane covers rows up to 5120 wide (the final LayerNorms of CogVideoX-5B at hidden 3072, modules/dit.py).
+template <class T, int CPL = 5>
 STAR_GLOBAL void ln_kernel(const LnParams p) {
-  constexpr int CPL = 5;
   const int lane = threadIdx.x & 63;
   const int LPR = p.lpr;                       // lanes per row (power of two)
   const int sub = lane & (LPR - 1), rowi = lane / LPR, rpw = 64 / LPR;

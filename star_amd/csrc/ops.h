@@ -72,7 +72,8 @@ int op_resize_pad(Ctx* ctx, const float* src, float* dst, int planes, int h, int
                   int pad_l, int pad_r, int pad_t, int pad_b, float pad_value);
 int op_plane_stats(Ctx* ctx, const float* x, float* stats, int planes, long long n, float scale, float shift,
                    bool clamp01, float eps);
-int op_color_fix(Ctx* ctx, const float* x, bool from_model, const float* src, float* out, int F, int C, int H, int W, int h, int w);
+int op_color_fix(Ctx* ctx, const float* x, bool from_model, const float* src, float* out, int F, int C, int H, int W, int h, int w,
+                 unsigned char* out_u8 = nullptr);
 int op_time_conv_out(Ctx* ctx, const float* rows, int ld, float* out, const float* w, const float* b, int F, int HW, int C);
 int op_rows_to_latent(Ctx* ctx, const float* rows, float* out, int Cl, int ld, long long ntok);
 int op_gemv(Ctx* ctx, const float* x, const void* W, const float* b, float* y, int N, int K, bool silu_in, bool silu_out);

@@ -591,16 +591,21 @@ void rt_note_launch_error(const char* what);
 #define STAR_LAUNCH(kern, grid, block, smem, stream, ...) \
   ::star_emu::launch((grid), (block), (smem), [&]() { kern(__VA_ARGS__); })
 #else
-// The dynamic-LDS opt-in (> 64 KB) is set once per kernel instantiation and call site, and a refused attribute or launch is
-// remembered in star::rt::launch_error (checked at the end of every C-ABI call: include/star_hip.h), never dropped.
+// The dynamic-LDS opt-in (> 64 KB) is a per-DEVICE property of the function object: it is cached per kernel instantiation, call
+// site and device (a process may hold contexts on several GPUs; the cache is a racy-but-idempotent hint: at worst the attribute
+// is set twice).  A refused attribute or launch is remembered in star::rt::launch_error (checked at the end of every C-ABI call:
+// include/star_hip.h), never dropped.
 #define STAR_LAUNCH(kern, grid, block, smem, stream, ...)                                              \
   do {                                                                                                  \
     if ((smem) > 65536) {                                                                               \
-      static size_t star_attr_set_ = 0;                                                                 \
-      if ((size_t)(smem) > star_attr_set_) {                                                            \
+      static size_t star_attr_set_[16] = {0};                                                           \
+      int star_dev_ = 0;                                                                                \
+      (void)hipGetDevice(&star_dev_);                                                                   \
+      size_t& star_cur_ = star_attr_set_[star_dev_ & 15];                                               \
+      if ((size_t)(smem) > star_cur_) {                                                                 \
         if (hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(smem)) != hipSuccess) \
           ::star::rt_note_launch_error(#kern ": dynamic LDS size refused");                             \
-        star_attr_set_ = (size_t)(smem);                                                                \
+        star_cur_ = (size_t)(smem);                                                                     \
       }                                                                                                 \
     }                                                                                                   \
     (void)hipGetLastError();   /* a stale error of an earlier call (e.g. a failed hipMalloc the pool recovered from) is not ours */ \

@@ -35,11 +35,12 @@ def resize_pad(video, target_hw, padding, value=1.0, ctx=None):
     return ctx.resize_pad(_on(ctx, video), target_hw, padding, value)
 
 
-def tensor2vid_color_fix(video, source, ctx=None):
+def tensor2vid_color_fix(video, source, ctx=None, as_uint8=False):
     """tensor2vid followed by adain_color_fix in one pass over the frames: video [1, C, F, H, W] in ~[-1, 1] (as
-    VideoToVideo_sr.test returns it), source [F, C, h, w] in [-1, 1]  ->  fp32 [F, H, W, C] in [0, 255] on video's device."""
+    VideoToVideo_sr.test returns it), source [F, C, h, w] in [-1, 1]  ->  fp32 [F, H, W, C] in [0, 255] on video's device;
+    as_uint8: the uint8 frames save_video would make of them (truncation, inference_utils.py:92) -- what the CLI moves off the GPU."""
     ctx = ctx or context_for(video.device if video.is_cuda else None)
-    out = ctx.color_fix(_on(ctx, video), _on(ctx, source))
+    out = ctx.color_fix(_on(ctx, video), _on(ctx, source), as_uint8=as_uint8)
     return out if video.is_cuda else out.cpu()
 
 

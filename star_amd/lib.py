@@ -117,6 +117,7 @@ class Library:
         self.resize_pad = _sig(c, "star_resize_pad", i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32)
         self.plane_stats = _sig(c, "star_plane_stats", i32, vp, vp, vp, i32, i64, f32, f32, i32, f32)
         self.color_fix = _sig(c, "star_color_fix", i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32)
+        self.color_fix_u8 = _sig(c, "star_color_fix_u8", i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32)
         self.adain_color_fix = _sig(c, "star_adain_color_fix", i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32)
         self.profile_begin = _sig(c, "star_profile_begin", i32, vp)
         self.profile_end = _sig(c, "star_profile_end", i32, vp, ctypes.POINTER(ProfEntry))
@@ -365,17 +366,18 @@ class Context:
                     "plane_stats")
         return out
 
-    def color_fix(self, video, source):
+    def color_fix(self, video, source, as_uint8=False):
         """tensor2vid + adain_color_fix (inference_utils.py:16-23, color_fix.py:15-29).  video: fp32 [1, C, F, H, W];
-        source: fp32 [F, C, h, w] in [-1, 1]  ->  fp32 [F, H, W, C] in [0, 255]."""
+        source: fp32 [F, C, h, w] in [-1, 1]  ->  fp32 [F, H, W, C] in [0, 255], or (as_uint8) the uint8 frames save_video's
+        `.astype('uint8')` makes of them (inference_utils.py:92), truncated on the GPU."""
         self._chk_tensor(video, torch.float32); self._chk_tensor(source, torch.float32)
         video, source = video.contiguous(), source.contiguous()
         assert video.dim() == 5 and video.shape[0] == 1 and source.dim() == 4
         _, C, F_, H, W = video.shape
         assert source.shape[0] == F_ and source.shape[1] == C, "video and source disagree on frames / channels"
-        out = torch.empty(F_, H, W, C, dtype=torch.float32, device=self.torch_device)
-        self._check(self.lib.color_fix(self.h, _ptr(video), _ptr(source), _ptr(out), F_, C, H, W, source.shape[2], source.shape[3]),
-                    "color_fix")
+        out = torch.empty(F_, H, W, C, dtype=torch.uint8 if as_uint8 else torch.float32, device=self.torch_device)
+        fn = self.lib.color_fix_u8 if as_uint8 else self.lib.color_fix
+        self._check(fn(self.h, _ptr(video), _ptr(source), _ptr(out), F_, C, H, W, source.shape[2], source.shape[3]), "color_fix")
         return out
 
     def adain_color_fix(self, target, source):

@@ -52,7 +52,9 @@ class _RaggedPlan:
             mine[j] = q.shape[dim]
         sizes = _gather_ints(mine, group, device)
         self.sizes = [[int(sizes[r, j]) for j in range(int(heads[r, 0]))] for r in range(world)]
-        owner = next(r for r in range(world) if int(heads[r, 0]) > 0)
+        owner = next((r for r in range(world) if int(heads[r, 0]) > 0), None)
+        if owner is None:
+            raise ValueError("ragged all-gather: no rank owns a part (empty chunk / frame list on every rank)")
         nd = int(heads[owner, 1])
         self.dtype = _DTYPES[int(heads[owner, 2])]
         self.pad_shape = [int(v) for v in heads[owner, 3:3 + nd]]

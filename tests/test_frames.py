@@ -63,6 +63,9 @@ def test_color_fix_vs_reference(ctx, name):
     assert out.shape == g["color_fix"].shape and out.dtype == torch.float32
     assert float((out - g["color_fix"]).abs().max()) <= 5e-3      # 0..255 scale: 2e-5 of the range
     assert float(out.min()) >= 0.0 and float(out.max()) <= 255.0
+    # the uint8 form the CLI moves off the GPU = save_video's `.astype('uint8')` (truncation) of the very same fp32 values
+    u8 = ctx.color_fix(video.to(dev), lr.to(dev), as_uint8=True).cpu()
+    assert u8.dtype == torch.uint8 and torch.equal(u8, out.to(torch.uint8))
     # the reference's two-call form: tensor2vid on the host side, adain_color_fix as its own entry point
     alone = ctx.adain_color_fix(fo.tensor2vid(video).contiguous().to(dev), lr.to(dev)).cpu()
     assert float((alone - g["color_fix"]).abs().max()) <= 5e-3

@@ -43,3 +43,45 @@ def test_save_video_streams_raw_frames_into_ffmpeg(tmp_path, monkeypatch):
     path = iu.save_video(vid, str(tmp_path / "out"), "b.mp4", fps=8)
     assert path.endswith("b.mp4")
     assert open(path, "rb").read() == vid.numpy().tobytes()
+
+
+def _fake_decoder(tmp_path, w, h, rate, payload, rc=0):
+    """a stand-in ffprobe / ffmpeg pair in one directory: the probe prints `w,h,rate`, the decoder writes `payload` to stdout"""
+    d = tmp_path / "bin"
+    d.mkdir()
+    raw = tmp_path / "raw.bin"
+    raw.write_bytes(payload)
+    (d / "ffprobe").write_text(f"#!/bin/sh\necho '{w},{h},{rate}'\n")
+    (d / "ffmpeg").write_text(f"#!/bin/sh\ncat '{raw}'\nexit {rc}\n")
+    for f in ("ffprobe", "ffmpeg"):
+        (d / f).chmod(0o755)
+    return str(d / "ffmpeg")
+
+
+def test_ffmpeg_decode_path_streams_frames_and_finds_ffprobe_next_to_ffmpeg(tmp_path, monkeypatch):
+    """round-2 advisor: the probe path was derived with str.replace over the whole path, no return code was checked and the
+    clip was captured whole.  Stand-in binaries in a directory whose NAME contains 'ffmpeg' (the str.replace trap)."""
+    base = tmp_path / "opt_ffmpeg_6"
+    base.mkdir()
+    bgr = (np.random.RandomState(1).rand(3, 4, 6, 3) * 255).astype(np.uint8)
+    exe = _fake_decoder(base, 6, 4, "30000/1001", bgr.tobytes())
+    monkeypatch.setattr(iu, "_ffmpeg", lambda: exe)
+    assert iu._ffprobe() == os.path.join(os.path.dirname(exe), "ffprobe")
+    frames, fps = iu._load_video_ffmpeg("clip.mp4")
+    assert len(frames) == 3 and all(np.array_equal(f, b) for f, b in zip(frames, bgr)) and abs(fps - 30000 / 1001) < 1e-9
+
+
+def test_ffmpeg_decode_errors_are_reported(tmp_path, monkeypatch):
+    import pytest
+    a = tmp_path / "a"
+    a.mkdir()
+    exe = _fake_decoder(a, 6, 4, "25/1", b"x" * (6 * 4 * 3 + 5))            # a torn last frame
+    monkeypatch.setattr(iu, "_ffmpeg", lambda: exe)
+    with pytest.raises(RuntimeError, match="stray bytes"):
+        iu._load_video_ffmpeg("clip.mp4")
+    b = tmp_path / "b"
+    b.mkdir()
+    exe2 = _fake_decoder(b, 6, 4, "0/0", b"y" * (6 * 4 * 3))                 # an unusable r_frame_rate
+    monkeypatch.setattr(iu, "_ffmpeg", lambda: exe2)
+    with pytest.raises(RuntimeError, match="frame rate"):
+        iu._load_video_ffmpeg("clip.mp4")

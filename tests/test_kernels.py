@@ -451,7 +451,7 @@ def test_group_norm_large_mean(ctx, dtype):
     assert_close(out, ref, dtype, scale=8.0, what="gn large mean")
 
 
-@pytest.mark.parametrize("C", [320, 512, 640, 1280, 2560])
+@pytest.mark.parametrize("C", [320, 512, 640, 1280, 2560, 3072, 5120])   # 3072 = CogVideoX-5B hidden (final LayerNorms of modules/dit.py)
 def test_layer_norm_and_liem_gates(ctx, dtype, C):
     g = torch.Generator().manual_seed(C + 1)
     Fr, H, W = 2, 6, 5
