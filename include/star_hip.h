@@ -78,6 +78,9 @@ typedef struct star_attn_desc {
   float scale;
   int32_t variant;                   /* 9 = the product kernel (0 is accepted as "default" = 9); any other id is rejected unless
                                         the library was built with -DSTAR_BENCH_VARIANTS (some ablation ids compute wrong results) */
+  int32_t causal;                    /* 1: key j is visible to query i only for j <= i (Nq == Nk): open_clip's text attn_mask,
+                                        embedder.py:59 */
+  int32_t reserved;                  /* 0 */
 } star_attn_desc;
 int star_attn_fwd(star_ctx* ctx, const star_attn_desc* d);
 
@@ -197,6 +200,15 @@ int star_color_fix_u8(star_ctx* ctx, const float* x, const float* src, uint8_t* 
  * (a tensor2vid result), src as above -> out fp32 device [F, H, W, C] in [0, 255]. */
 int star_adain_color_fix(star_ctx* ctx, const float* target, const float* src, float* out, int32_t F, int32_t C, int32_t H,
                          int32_t W, int32_t h, int32_t w);
+
+/* ---- OpenCLIP ViT-H/14 text tower --------------------------------------------------------------
+ * replaces: FrozenOpenCLIPEmbedder.text_transformer_forward + ln_final (video_to_video/modules/embedder.py:53-72) on the tensors
+ * staged with star_load_tensor under open_clip's names (transformer.resblocks.{i}.{ln_1,ln_2}.{weight,bias},
+ * .attn.in_proj_{weight,bias}, .attn.out_proj.*, .mlp.c_fc.*, .mlp.c_proj.*, ln_final.*).
+ * star_text_forward: x = token_embedding(tokens) + positional_embedding as [batch * tokens, width] rows in the context's 16-bit
+ * type; the first run_layers blocks run (layers - 1 for layer = 'penultimate'), causal self-attention, then ln_final; out like x. */
+int star_text_build(star_ctx* ctx, int32_t width, int32_t heads, int32_t layers);
+int star_text_forward(star_ctx* ctx, const void* x, int32_t batch, int32_t tokens, int32_t run_layers, void* out);
 
 /* ---- live per-kernel-family timing (HIP events on the launch stream; used by bench.py's roofline leg) --------- */
 enum { STAR_PK_ATTN_SELF = 0, STAR_PK_ATTN_CROSS, STAR_PK_TATTN, STAR_PK_GEMM, STAR_PK_CONV, STAR_PK_TCONV, STAR_PK_GN,

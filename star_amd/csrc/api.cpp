@@ -12,6 +12,9 @@ namespace star {
 int dit_build(Ctx* ctx, int D, int heads, int E, int n_layers, float ln_eps);
 int dit_block_forward(Ctx* ctx, int layer, const void* x_in, const float* emb, void* x_out, int text_len, int T, int H, int W);
 void dit_release(Ctx* ctx);
+void text_release(Ctx* ctx);
+int text_build(Ctx* ctx, int W, int heads, int n_layers);
+int text_forward(Ctx* ctx, const void* x_in, int batch, int tokens, int run_layers, void* out);
 }
 
 struct star_ctx { Ctx c; };
@@ -81,6 +84,7 @@ void star_ctx_destroy(star_ctx* h) {
   h->c.unet.reset();
   h->c.vae.reset();
   dit_release(&h->c);
+  text_release(&h->c);
   h->c.pool.release();
   if (h->c.zero_page) rt::dev_free(h->c.zero_page);
   delete h;
@@ -130,7 +134,7 @@ int star_attn_fwd(star_ctx* h, const star_attn_desc* d) {
   a.Q = d->Q; a.K = d->K; a.V = d->V; a.O = d->O;
   a.ldq = d->ldq; a.ldk = d->ldk; a.ldv = d->ldv; a.ldo = d->ldo;
   a.bsq = d->bsq; a.bsk = d->bsk; a.bsv = d->bsv; a.bso = d->bso;
-  a.Nq = d->Nq; a.Nk = d->Nk; a.heads = d->heads; a.batch = d->batch; a.scale = d->scale; a.variant = d->variant ? d->variant : 9;
+  a.Nq = d->Nq; a.Nk = d->Nk; a.heads = d->heads; a.batch = d->batch; a.scale = d->scale; a.variant = d->variant ? d->variant : 9; a.causal = d->causal;
   return finish(h, op_flash_attn(&h->c, a));
 }
 int star_temporal_attn_fwd(star_ctx* h, const star_tattn_desc* d) {
@@ -320,6 +324,18 @@ int star_profile_end(star_ctx* h, star_prof_entry* out) {
   h->c.prof.clear();
   h->c.profiling = false;
   return 0;
+}
+
+int star_text_build(star_ctx* h, int32_t width, int32_t heads, int32_t layers) {
+  if (!h) return -1;
+  rt::set_device(h->c.device);
+  return finish(h, text_build(&h->c, width, heads, layers));
+}
+int star_text_forward(star_ctx* h, const void* x, int32_t batch, int32_t tokens, int32_t run_layers, void* out) {
+  if (!h) return -1;
+  rt::set_device(h->c.device);
+  if (!x || !out) return finish(h, h->c.fail("text_forward: null pointer"));
+  return finish(h, text_forward(&h->c, x, batch, tokens, run_layers, out));
 }
 
 }  // extern "C"

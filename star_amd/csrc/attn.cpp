@@ -36,6 +36,12 @@ static int launch_flash(Ctx* ctx, const AttnArgs& a) {
     }
   }
 #endif
+  if (a.causal) {   // text tower: 77 tokens, causal mask (embedder.py:59)
+    if (a.variant != 9) return ctx->fail("flash_attn: the causal mask exists in the product kernel only");
+    if (a.Nq != a.Nk) return ctx->fail("flash_attn: the causal mask needs Nq == Nk");
+    STAR_LAUNCH((flash_attn_v5_kernel<T, 0, 1, 1>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);
+    return 0;
+  }
   if (a.variant == 9) {   // the shipped kernel (attn5.h).  Packed 16-bit row sums only where hundreds of key tiles average their
                           // rounding out (spatial self-attention); the 77-token cross-attention keeps fp32 row sums
     if constexpr (__is_same(T, f16)) {

@@ -35,7 +35,9 @@ STAR_DEV vec<T, 2> pk_add(vec<T, 2> a, vec<T, 2> b) {
 #endif
 }
 
-template <class T, int PKSUM, int AUGK8 = 0>   // AUGK8: the augmented k-step as a half-depth 32x32x8 MFMA (one useful k of 8 instead of 16: +1-4 %, bit-identical; shipped)
+// CAUSAL = 1 (text tower, embedder.py:59: open_clip's attn_mask): key j is visible to query i only for j <= i; Nq == Nk, the mask
+// is applied to the scores of every tile (and again on the recompute path), so masked probabilities are exact zeros.
+template <class T, int PKSUM, int AUGK8 = 0, int CAUSAL = 0>   // AUGK8: the augmented k-step as a half-depth 32x32x8 MFMA (one useful k of 8 instead of 16: +1-4 %, bit-identical; shipped)
 STAR_GLOBAL void STAR_LAUNCH_BOUNDS(256, 2)
 flash_attn_v5_kernel(const AttnParams p) {
   constexpr int NQ = 2, QW = 64, QB = 256, KT = 64, TILE = KT * 128, BUFB = 2 * TILE;   // one buffer = K tile | V tile (16 KB)
@@ -187,6 +189,18 @@ flash_attn_v5_kernel(const AttnParams p) {
             if (key >= p.Nk) {
 #pragma unroll
               for (int qi = 0; qi < NQ; ++qi) s[qi][kb][r] = -1e30f;
+            }
+          }
+      }
+      if constexpr (CAUSAL != 0) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = t * KT + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
+#pragma unroll
+            for (int qi = 0; qi < NQ; ++qi) {
+              if (key > q_base + qi * 32 + lq) s[qi][kb][r] = -1e30f;
             }
           }
       }

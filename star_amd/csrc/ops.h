@@ -45,6 +45,7 @@ struct AttnArgs {
   long long bsq = 0, bsk = 0, bsv = 0, bso = 0;
   int Nq = 0, Nk = 0, heads = 0, batch = 0;
   float scale = 0.125f;
+  int causal = 0;    // 1: key j visible to query i only for j <= i (Nq == Nk; the text tower)
   int variant = 9;   // 0 baseline, 1 v2, 2 v3, 3 v3 with 4 waves/SIMD, 4/5 software-pipelined, 6 v3 + lazy maxima, 7 lazy maxima probed per
                      // query block, 8 key-half pipeline, 9 = 6 with fp32-add row sums (default: fastest in the A/Bs, profiles/r01_attn_ab.txt)
 };

@@ -33,7 +33,7 @@ class AttnDesc(ctypes.Structure):
         ("ldq", ctypes.c_int32), ("ldk", ctypes.c_int32), ("ldv", ctypes.c_int32), ("ldo", ctypes.c_int32),
         ("bsq", ctypes.c_int64), ("bsk", ctypes.c_int64), ("bsv", ctypes.c_int64), ("bso", ctypes.c_int64),
         ("Nq", ctypes.c_int32), ("Nk", ctypes.c_int32), ("heads", ctypes.c_int32), ("batch", ctypes.c_int32),
-        ("scale", ctypes.c_float), ("variant", ctypes.c_int32),
+        ("scale", ctypes.c_float), ("variant", ctypes.c_int32), ("causal", ctypes.c_int32), ("reserved", ctypes.c_int32),
     ]
 
 
@@ -117,6 +117,8 @@ class Library:
         self.resize_pad = _sig(c, "star_resize_pad", i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32)
         self.plane_stats = _sig(c, "star_plane_stats", i32, vp, vp, vp, i32, i64, f32, f32, i32, f32)
         self.color_fix = _sig(c, "star_color_fix", i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32)
+        self.text_build = _sig(c, "star_text_build", i32, vp, i32, i32, i32)
+        self.text_forward = _sig(c, "star_text_forward", i32, vp, vp, i32, i32, i32, vp)
         self.color_fix_u8 = _sig(c, "star_color_fix_u8", i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32)
         self.adain_color_fix = _sig(c, "star_adain_color_fix", i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32)
         self.profile_begin = _sig(c, "star_profile_begin", i32, vp)
@@ -244,7 +246,7 @@ class Context:
         self._check(self.lib.gemm(self.h, ctypes.byref(d)), "gemm")
         return out
 
-    def attention(self, q, k, v, heads, out=None, scale=None, variant=9):
+    def attention(self, q, k, v, heads, out=None, scale=None, variant=9, causal=False):
         """softmax(q k^T * scale) v per (batch, head).  q: [B, Nq, heads*64]; k, v: [B or 1, Nk, heads*64]
         (a leading dim of 1 is shared by all batches).  Views with a row stride are fine (fused QKV buffers)."""
         for t in (q, k, v):
@@ -263,6 +265,7 @@ class Context:
         d.Nq, d.Nk, d.heads, d.batch = Nq, Nk, heads, B
         d.scale = float(scale if scale is not None else 64 ** -0.5)
         d.variant = variant
+        d.causal = 1 if causal else 0
         self._check(self.lib.attn_fwd(self.h, ctypes.byref(d)), "attn_fwd")
         return out
 

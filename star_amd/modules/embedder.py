@@ -3,7 +3,14 @@
 The reference runs OpenCLIP ViT-H/14's text tower (24 pre-LN blocks, width 1024, 16 heads, 77 tokens, causal mask), stops
 one block early (`layer='penultimate'`) and applies `ln_final`: a `[1, 77, 1024]` tensor per prompt, twice per video
 (positive and negative prompt).  It is host-side orchestration, not part of the per-chunk hot path (SURVEY.md section 8f
-rank 3), so it stays PyTorch here:
+rank 3).  Two execution paths for the 23 transformer blocks + ln_final:
+
+  * `runtime="hip"` (default whenever the embedder sits on a GPU): the tower runs on the SAME runtime as the denoiser --
+    star_text_build / star_text_forward in libstar_hip.so (star_amd/csrc/text.cpp): star's GEMM, LayerNorm and flash-attention
+    kernels, the latter with the causal mask added for this; only the token-embedding gather stays in torch;
+  * `runtime="torch"`: the nn.Module below, used on the CPU and as the parity reference of the HIP path in the tests.
+
+Where the model and the tokenizer come from:
 
   * with `open_clip` installed the wrapper builds the same model the reference builds (`create_model_and_transforms`,
     visual tower deleted) and tokenises with `open_clip.tokenize`;
@@ -12,10 +19,10 @@ rank 3), so it stays PyTorch here:
     any callable `str | list[str] -> LongTensor[B, 77]` serves as the tokenizer.  The BPE vocabulary ships only inside the
     open_clip package, so a prompt STRING cannot be tokenised without it -- that case raises ImportError with this text.
 
-PARITY UNPINNED for the restated tower: open_clip is not installed here, tests/test_embedder.py pins it against an
-independent statement of the same block on torch.nn.functional.multi_head_attention_forward only.
+PARITY UNPINNED for the restated tower: open_clip is not installed here; tests/test_embedder.py checks the nn.Module against an
+independent statement of the block (on torch.nn.functional.multi_head_attention_forward, kept with the test infrastructure) and the HIP path
+against the nn.Module.
 """
-import math
 from collections import OrderedDict
 
 import torch
@@ -74,9 +81,11 @@ class FrozenOpenCLIPEmbedder(nn.Module):
     LAYERS = ["last", "penultimate"]
 
     def __init__(self, pretrained="laion2b_s32b_b79k", arch="ViT-H-14", device="cuda", max_length=77, freeze=True,
-                 layer="penultimate", model=None, tokenizer=None, text_state_dict=None):
+                 layer="penultimate", model=None, tokenizer=None, text_state_dict=None, runtime=None, dtype=torch.float16, library=None):
         super().__init__()
         assert layer in self.LAYERS
+        assert runtime in (None, "hip", "torch")
+        self._runtime, self._hip_dtype, self._library, self._hip = runtime, dtype, library, None
         if model is None and text_state_dict is not None:
             if isinstance(text_state_dict, str):
                 text_state_dict = torch.load(text_state_dict, map_location="cpu")
@@ -113,9 +122,44 @@ class FrozenOpenCLIPEmbedder(nn.Module):
         tokens = self.tokenizer(text)
         return self.encode_with_transformer(tokens.to(self.device))
 
+    def _use_hip(self):
+        if self._runtime is not None:
+            return self._runtime == "hip"
+        return torch.device(self.device).type == "cuda" or self._library is not None
+
+    def _hip_tower(self):
+        """stage the tower's weights once (open_clip names) and build it on the device context: star_text_build"""
+        if self._hip is None:
+            from .. import lib as L
+            from .unet_v2v import stage_tensor
+            dev = torch.device(self.device)
+            ctx = L.Context(dev.index or 0, self._hip_dtype, self._library)
+            sd = self.model.state_dict()
+            blocks = self.model.transformer.resblocks
+            keys = ["ln_final.weight", "ln_final.bias"]
+            for i in range(len(blocks)):
+                keys += [f"transformer.resblocks.{i}.{n}" for n in ("ln_1.weight", "ln_1.bias", "ln_2.weight", "ln_2.bias", "attn.in_proj_weight",
+                                                                     "attn.in_proj_bias", "attn.out_proj.weight", "attn.out_proj.bias", "mlp.c_fc.weight",
+                                                                     "mlp.c_fc.bias", "mlp.c_proj.weight", "mlp.c_proj.bias")]
+            for k in keys:
+                stage_tensor(ctx, k, sd[k])
+            width = self.model.ln_final.weight.shape[0]
+            heads = blocks[0].attn.num_heads
+            ctx._check(ctx.lib.text_build(ctx.h, int(width), int(heads), len(blocks)), "text_build")
+            self._hip = (ctx, L, width, len(blocks))
+        return self._hip
+
     def encode_with_transformer(self, text):
         x = self.model.token_embedding(text)             # [B, 77, W]
         x = x + self.model.positional_embedding
+        if self._use_hip():                              # blocks + ln_final on the HIP runtime (star_amd/csrc/text.cpp)
+            ctx, L, width, n_blocks = self._hip_tower()
+            ctx.use_current_stream()
+            B, T, _ = x.shape
+            xin = x.to(device=ctx.torch_device, dtype=self._hip_dtype).reshape(B * T, width).contiguous()
+            out = torch.empty_like(xin)
+            ctx._check(ctx.lib.text_forward(ctx.h, L._ptr(xin), B, T, n_blocks - self.layer_idx, L._ptr(out)), "text_forward")
+            return out.reshape(B, T, width).float()
         x = x.permute(1, 0, 2)                           # NLD -> LND
         x = self.text_transformer_forward(x, attn_mask=self.model.attn_mask)
         x = x.permute(1, 0, 2)
@@ -131,16 +175,3 @@ class FrozenOpenCLIPEmbedder(nn.Module):
 
     def encode(self, text):
         return self(text)
-
-
-def reference_block(x, p, heads, mask):
-    """independent statement of one block on F.multi_head_attention_forward (tests only; x: [L, B, W], p: dict of tensors)."""
-    h = F.layer_norm(x, x.shape[-1:], p["ln_1.weight"], p["ln_1.bias"])
-    a, _ = F.multi_head_attention_forward(h, h, h, x.shape[-1], heads, p["attn.in_proj_weight"], p["attn.in_proj_bias"], None, None,
-                                          False, 0.0, p["attn.out_proj.weight"], p["attn.out_proj.bias"], training=False,
-                                          need_weights=False, attn_mask=mask)
-    x = x + a
-    h = F.layer_norm(x, x.shape[-1:], p["ln_2.weight"], p["ln_2.bias"])
-    h = F.linear(h, p["mlp.c_fc.weight"], p["mlp.c_fc.bias"])
-    h = 0.5 * h * (1.0 + torch.erf(h / math.sqrt(2.0)))
-    return x + F.linear(h, p["mlp.c_proj.weight"], p["mlp.c_proj.bias"])

@@ -1,17 +1,23 @@
 """Text-encoder wrapper (star_amd/modules/embedder.py; reference video_to_video/modules/embedder.py:12-72): the prompt-string path
 with a stub tokenizer, the penultimate-layer rule, the causal mask, and the restated OpenCLIP text block against an independent
 statement on F.multi_head_attention_forward.  open_clip is not installed in this image: PARITY UNPINNED against open_clip itself."""
+import os
+import sys
+
 import pytest
 import torch
 
-from star_amd.modules.embedder import FrozenOpenCLIPEmbedder, OpenCLIPTextTransformer, reference_block
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+from text_oracle import reference_block  # noqa: E402
+from star_amd.modules.embedder import FrozenOpenCLIPEmbedder, OpenCLIPTextTransformer  # noqa: E402
+from util import BACKENDS  # noqa: E402
 
 torch.set_grad_enabled(False)
 
 
-def small_tower(layers=3):
+def small_tower(layers=3, width=64, heads=4):
     torch.manual_seed(0)
-    m = OpenCLIPTextTransformer(vocab_size=100, context_length=77, width=64, heads=4, layers=layers)
+    m = OpenCLIPTextTransformer(vocab_size=100, context_length=77, width=width, heads=heads, layers=layers)
     for p in m.parameters():
         if p.dim() == 1:
             p.add_(torch.randn_like(p) * 0.1)
@@ -29,7 +35,7 @@ def tok(text):
 
 def test_prompt_string_goes_through_tokenizer_and_stops_one_block_early():
     m = small_tower(3)
-    emb = FrozenOpenCLIPEmbedder(device="cpu", model=m, tokenizer=tok)
+    emb = FrozenOpenCLIPEmbedder(device="cpu", model=m, tokenizer=tok, runtime="torch")
     z = emb("a cat")
     assert z.shape == (1, 77, 64) and z.dtype == torch.float32
     sd = {k: v for k, v in m.state_dict().items()}
@@ -39,13 +45,13 @@ def test_prompt_string_goes_through_tokenizer_and_stops_one_block_early():
         x = reference_block(x, p, 4, m.attn_mask)
     ref = torch.nn.functional.layer_norm(x.permute(1, 0, 2), (64,), sd["ln_final.weight"], sd["ln_final.bias"])
     assert float((z - ref).abs().max()) < 2e-5
-    last = FrozenOpenCLIPEmbedder(device="cpu", model=m, tokenizer=tok, layer="last")("a cat")
+    last = FrozenOpenCLIPEmbedder(device="cpu", model=m, tokenizer=tok, layer="last", runtime="torch")("a cat")
     assert float((last - z).abs().max()) > 1e-3
 
 
 def test_causal_mask_later_tokens_do_not_leak_backwards():
     m = small_tower(2)
-    emb = FrozenOpenCLIPEmbedder(device="cpu", model=m, tokenizer=tok, layer="last")
+    emb = FrozenOpenCLIPEmbedder(device="cpu", model=m, tokenizer=tok, layer="last", runtime="torch")
     a, b = emb("hello world"), emb("hello there")
     assert float((a[0, :6] - b[0, :6]).abs().max()) == 0.0      # <start> + "hello" are identical, what follows must not matter
     assert float((a[0, 8:] - b[0, 8:]).abs().max()) > 0
@@ -68,3 +74,49 @@ def test_missing_open_clip_is_reported_only_when_a_string_needs_it():
         pass
     with pytest.raises(ImportError):
         FrozenOpenCLIPEmbedder(device="cpu")
+
+
+def _rel(a, b):
+    return float((a.float().cpu() - b.float().cpu()).pow(2).mean().sqrt() / b.float().cpu().pow(2).mean().sqrt())
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+def test_text_tower_on_the_hip_runtime_matches_the_torch_tower(backend, dtype, request):
+    """the blocks + ln_final through star_text_forward (GEMM, LayerNorm, causal flash attention of
+    libstar_hip.so) against the nn.Module restatement in fp32; penultimate and last layer; two prompts of different length (the
+    causal mask is what keeps the padding behind the end token from leaking forward)."""
+    emu = request.getfixturevalue("emu_lib") if backend == "emu" else None
+    m = small_tower(3, width=128, heads=2)
+    ref = FrozenOpenCLIPEmbedder(device="cpu", model=m, tokenizer=tok, runtime="torch")(["a cat", "a much longer prompt about a dog"])
+    dev = "cpu" if backend == "emu" else "cuda:0"
+    for layer in ("penultimate", "last"):
+        want = ref if layer == "penultimate" else FrozenOpenCLIPEmbedder(device="cpu", model=m, tokenizer=tok, runtime="torch", layer="last")(
+            ["a cat", "a much longer prompt about a dog"])
+        hip = FrozenOpenCLIPEmbedder(device=dev, model=small_tower(3, width=128, heads=2), tokenizer=tok, runtime="hip", dtype=dtype, library=emu,
+                                     layer=layer)
+        z = hip(["a cat", "a much longer prompt about a dog"])
+        assert z.shape == (2, 77, 128) and z.dtype == torch.float32 and torch.isfinite(z).all()
+        assert _rel(z, want) < (4e-3 if dtype == torch.float16 else 3e-2), (layer, _rel(z, want))
+    a = hip(["hello world"])
+    b = hip(["hello there"])
+    assert float((a[0, :6] - b[0, :6]).abs().max()) == 0.0 and float((a[0, 8:] - b[0, 8:]).abs().max()) > 0      # causal on the HIP path too
+
+
+@pytest.mark.gpu
+def test_full_size_text_tower_on_the_gpu():
+    """ViT-H/14 text tower at its real size (24 blocks, width 1024, 16 heads), random weights, fp16 on the HIP runtime vs the fp32
+    torch tower; `penultimate` as the pipeline uses it (embedder.py:24)."""
+    torch.manual_seed(1)
+    m = OpenCLIPTextTransformer()
+    for p in m.parameters():
+        if p.dim() == 1:
+            p.add_(torch.randn_like(p) * 0.05)
+    tokens = torch.randint(3, 49000, (2, 77))
+    tokens[0, 20:] = 0
+    want = FrozenOpenCLIPEmbedder(device="cpu", model=m, tokenizer=lambda t: tokens, runtime="torch")("x")
+    hip = FrozenOpenCLIPEmbedder(device="cuda:0", model=m, tokenizer=lambda t: tokens)
+    assert hip._use_hip()
+    z = hip("x")
+    print(f"text tower, 23 blocks + ln_final, fp16 HIP vs fp32 torch: relative rms {_rel(z, want):.2e}")
+    assert z.shape == (2, 77, 1024) and torch.isfinite(z).all() and _rel(z, want) < 1e-2
