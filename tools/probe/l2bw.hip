@@ -18,7 +18,9 @@ __global__ void __launch_bounds__(512) k_fill(const char* __restrict__ src, size
   // workgroup b starts at a different offset so that the 32 CUs of an XCD do not walk in lock step over the same lines
   const size_t per_wave = 1024;                       // bytes per wave-instruction
   const size_t pieces = span / per_wave;              // pieces in the span
-  size_t p = ((size_t)blockIdx.x * 977 + wave * 131) % pieces;
+  // the WORKGROUP walks one fixed piece sequence (start + 7 k) mod pieces, k = 0, 1, ...; wave w takes k = w, w + nw, ... : the
+  // address stream a CU emits is the same for every wave count
+  size_t p = ((size_t)blockIdx.x * 977 + (size_t)wave * 7) % pieces;
   u4 acc = {0, 0, 0, 0};
   const unsigned ldsbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds + wave * (WIN * 1024);
   const long long t0 = __builtin_readcyclecounter();
@@ -70,11 +72,17 @@ int main() {
   setvbuf(stdout, NULL, _IONBF, 0);
   const size_t big = (size_t)1 << 30;
   char* src; CK(hipMalloc(&src, big)); CK(hipMemset(src, 1, big));
-  for (size_t span : {(size_t)1 << 20, (size_t)4 << 20, (size_t)16 << 20, (size_t)64 << 20, (size_t)192 << 20, (size_t)1 << 30}) {
+  for (size_t span : {(size_t)4 << 20, (size_t)16 << 20, (size_t)64 << 20, (size_t)192 << 20}) {
     const int reps = (int)(((size_t)4 << 30) / span);
     run<0, 8>("LDS-DMA, 8 waves, window 8", src, span, 8, reps);
-    run<0, 16>("LDS-DMA, 8 waves, window 16", src, span, 8, reps);
+    run<0, 4>("LDS-DMA, 8 waves, window 4", src, span, 8, reps);
+    run<0, 2>("LDS-DMA, 8 waves, window 2", src, span, 8, reps);
+    run<0, 16>("LDS-DMA, 4 waves, window 16", src, span, 4, reps);
     run<0, 8>("LDS-DMA, 4 waves, window 8", src, span, 4, reps);
+    run<0, 4>("LDS-DMA, 4 waves, window 4", src, span, 4, reps);
+    run<0, 16>("LDS-DMA, 2 waves, window 16", src, span, 2, reps);
+    run<0, 8>("LDS-DMA, 2 waves, window 8", src, span, 2, reps);
+    run<0, 16>("LDS-DMA, 1 wave, window 16", src, span, 1, reps);
   }
   return 0;
 }
