@@ -4,9 +4,6 @@
 #include "ops.h"
 #include "attn.h"
 #include "attn5.h"
-#ifdef STAR_BENCH_VARIANTS
-#include "attn_variants.h"
-#endif
 
 namespace star {
 
@@ -64,9 +61,7 @@ static int launch_flash(Ctx* ctx, const AttnArgs& a) {
     else return ctx->fail("flash_attn: variant 31 (packed row sums) is f16 only");
   }
   // measured-and-lost A/B variants and ablation probes (several compute deliberately wrong results): bench build / emulator only
-  if (a.variant == 0) STAR_LAUNCH((flash_attn_kernel<T>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);
-  else if (a.variant == 1) STAR_LAUNCH((flash_attn_v2_kernel<T>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);
-  else if (a.variant == 2) STAR_LAUNCH((flash_attn_v3_kernel<T, 2>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);
+  if (a.variant == 2) STAR_LAUNCH((flash_attn_v3_kernel<T, 2>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);
   else if (a.variant == 6) STAR_LAUNCH((flash_attn_v3_kernel<T, 2, 1>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);
   else if (a.variant == 7) STAR_LAUNCH((flash_attn_v3_kernel<T, 2, 2>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);
   else if (a.variant == 8) STAR_LAUNCH((flash_attn_v3_kernel<T, 2, 3>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);
@@ -85,22 +80,11 @@ static int launch_flash(Ctx* ctx, const AttnArgs& a) {
   else if (a.variant == 27) STAR_LAUNCH((flash_attn_v3_kernel<T, 2, 1, 0, 1, 0, 2>), dim3((unsigned)nblk), dim3(256), (size_t)65536, ctx->stream, p);   // key tiles in pairs: one barrier per 128 keys
   else if (a.variant == 21) STAR_LAUNCH((flash_attn_v3_kernel<T, 2, 1, 0, 1, 1>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p);
   else if (a.variant == 22) STAR_LAUNCH((flash_attn_v3_kernel<T, 2, 1, 0, 1, 0, 1>), dim3((unsigned)nblk), dim3(256), (size_t)(3 * 16384), ctx->stream, p);
-  else if (a.variant == 20) {   // enforced antiphase, 512-row workgroups
-    p.nqb = (a.Nq + 511) / 512;
-    const long long nblk5 = 8LL * p.nqb * ((BH + 7) / 8);
-    STAR_LAUNCH((flash_attn_v6_kernel<T>), dim3((unsigned)nblk5), dim3(512), (size_t)(5 * 8192), ctx->stream, p);
-  }
-  else if (a.variant == 4) {   // software-pipelined, 128-row workgroups
-    p.nqb = (a.Nq + 127) / 128;
-    const long long nblk4 = 8LL * p.nqb * ((BH + 7) / 8);
-    STAR_LAUNCH((flash_attn_v4_kernel<T, 1>), dim3((unsigned)nblk4), dim3(256), (size_t)(3 * 16384), ctx->stream, p);
-  } else if (a.variant == 5) {   // software-pipelined, 256-row workgroups, ONE wave per SIMD (512 registers)
-    STAR_LAUNCH((flash_attn_v4_kernel<T, 2>), dim3((unsigned)nblk), dim3(256), (size_t)(3 * 16384), ctx->stream, p);
-  } else {   // 128-row workgroups, 4 waves per SIMD
+  else if (a.variant == 3) {   // 128-row workgroups, 4 waves per SIMD
     p.nqb = (a.Nq + 127) / 128;
     const long long nblk4 = 8LL * p.nqb * ((BH + 7) / 8);
     STAR_LAUNCH((flash_attn_v3_kernel<T, 1>), dim3((unsigned)nblk4), dim3(256), (size_t)32768, ctx->stream, p);
-  }
+  } else return ctx->fail("flash_attn: unknown variant id (0 / 1 / 4 / 5 / 20, the first losers of round 1, were removed in round 3: git history)");
   return 0;
 #else
   return ctx->fail("flash_attn: variant ids other than 9 exist only in the bench build (make bench)");

@@ -10,12 +10,13 @@
 // The product ships ONE spatial kernel, flash_attn_v5_kernel (attn5.h, AttnArgs::variant 9): the algorithm of
 // flash_attn_v3_kernel<T, 2, LAZY=1, 0, ROWSUM=1> below (scale + running max folded into the MFMA, lazy row maxima with the
 // row sum of P as overflow probe) with the non-softmax VALU taken out of the key-tile loop (+9-16 %).  The v3 kernel itself
-// (variant 32, the product of rounds 1-2), its other template modes and the kernels in attn_variants.h are the measured A/B
+// (variant 32, the product of rounds 1-2) and its other template modes are the measured A/B
 // variants and ablation probes of profiles/r01_attn_ab.txt; they are instantiated only in the bench build
 // (-DSTAR_BENCH_VARIANTS) and the test emulator:
 //   2 / 3   v3 without lazy maxima (NQ = 2 / 1)      6 / 7   lazy maxima, one probe per tile / per block
 //   8       key-half pipeline      10 / 15  chunk pipeline      21 / 22  K fragments read ahead / K-V ring of three
-//   0 / 1 / 4 / 5 / 20   attn_variants.h           11-14, 16, 17  ablation probes (wrong results by construction)
+//   11-14, 16, 17  ablation probes (wrong results by construction)      40 / 41  attn7.h (round 3)
+// (variants 0 / 1 / 4 / 5 / 20 -- baseline, v2, the tile-level software pipelines and the antiphase kernel -- were removed in round 3)
 //
 // Both compute S^T = K Q^T with the MFMA operands swapped, so a lane owns one
 // query row: its 32 scores per 64-key tile sit in its own registers, the row max

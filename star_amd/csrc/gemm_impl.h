@@ -3,9 +3,6 @@
 #pragma once
 #include "ops.h"
 #include "gemm.h"
-#ifdef STAR_BENCH_VARIANTS
-#include "gemm8.h"
-#endif
 
 namespace star {
 
@@ -72,37 +69,6 @@ static int launch_gemm_t(Ctx* ctx, const GemmArgs& a) {
   return launch_gemm_f<T, BM, BN, WM, WN, MINW, false, STAGGER, PIPE, ALLEPI>(ctx, a);
 }
 
-#ifdef STAR_BENCH_VARIANTS
-// persistent phase-interleaved kernel (gemm8.h): one workgroup per CU walks its output tiles
-template <class T, bool RES, int ABL = 0>
-static int launch_gemm8_r(Ctx* ctx, const GemmArgs& a, int grid_cap) {
-  GemmParams p{};
-  p.A = a.A; p.W = a.W; p.C = a.C; p.bias = a.bias; p.res = a.res; p.zero_page = ctx->zero_page;
-  p.M = a.M; p.N = a.N; p.K = a.K; p.lda = a.lda; p.ldc = a.ldc; p.ldr = a.ldr;
-  p.H = a.H; p.Wd = a.Wd; p.Cin = a.Cin; p.Ho = a.Ho; p.Wo = a.Wo; p.stride = a.stride; p.pad_t = a.pad_t; p.pad_l = a.pad_l;
-  p.HW = a.HW; p.F = a.F; p.up_crop = a.up_crop; p.epi = a.epi;
-  p.tiles_m = (a.M + G8::BM - 1) / G8::BM;
-  p.tiles_n = (a.N + G8::BN - 1) / G8::BN;
-  const int nblk = p.tiles_m * p.tiles_n;
-  const int g = nblk <= grid_cap ? nblk : grid_cap;   // grid_cap is a multiple of 8 (XCD affinity of the tile walk)
-  dim3 grid((unsigned)g), block(G8::NT);
-  constexpr size_t smem = G8::SMEM_TOTAL;
-  switch (a.mode) {
-    case A_PLAIN: STAR_LAUNCH((gemm8_kernel<T, A_PLAIN, RES, ABL>), grid, block, smem, ctx->stream, p); break;
-    case A_CONV3X3: STAR_LAUNCH((gemm8_kernel<T, A_CONV3X3, RES, ABL>), grid, block, smem, ctx->stream, p); break;
-    case A_CONV3X3_UP: STAR_LAUNCH((gemm8_kernel<T, A_CONV3X3_UP, RES, ABL>), grid, block, smem, ctx->stream, p); break;
-    case A_TCONV3: STAR_LAUNCH((gemm8_kernel<T, A_TCONV3, RES, ABL>), grid, block, smem, ctx->stream, p); break;
-    default: return ctx->fail("gemm8: bad A mode");
-  }
-  return 0;
-}
-template <class T>
-static int launch_gemm8(Ctx* ctx, const GemmArgs& a, int grid_cap) {
-  return (a.epi & EPI_RES) ? launch_gemm8_r<T, true>(ctx, a, grid_cap) : launch_gemm8_r<T, false>(ctx, a, grid_cap);
-}
-
-#endif
-
 template <class T>
 static int launch_gemm(Ctx* ctx, const GemmArgs& a) {
   int tile = a.force_tile;
@@ -143,21 +109,6 @@ static int launch_gemm(Ctx* ctx, const GemmArgs& a) {
     // two independent 4-wave workgroups per CU (72 KB of LDS each): one group's epilogue and DMA latency hide behind the
     // other group's MFMA burst (auto-selected for the short-K GEGLU layers)
     case 9: return launch_gemm_t<T, 128, 256, 2, 2, 2, false, 3>(ctx, a);
-#ifdef STAR_BENCH_VARIANTS
-    // persistent phase-interleaved kernel (gemm8.h): correct and race-free on hardware, not faster than the 2-stage tiles on
-    // random operands (power-limited; profiles/r02_gemm8_ablation.txt).  fp32 output stays on the 2-stage tiles.
-    case 20: if (a.epi & EPI_OUT_F32) return launch_gemm_t<T, 256, 256, 4, 2, 2>(ctx, a); return launch_gemm8<T>(ctx, a, 256);
-    case 21: if (a.epi & EPI_OUT_F32) return launch_gemm_t<T, 256, 256, 4, 2, 2>(ctx, a); return launch_gemm8<T>(ctx, a, 8);   // 8 workgroups (tests: several output tiles per workgroup)
-    case 31: return launch_gemm8_r<T, false, 1>(ctx, a, 256);   // timing ablations of gemm8 (garbage results)
-    case 32: return launch_gemm8_r<T, false, 2>(ctx, a, 256);
-    case 33: return launch_gemm8_r<T, false, 3>(ctx, a, 256);
-    case 34: return launch_gemm8_r<T, false, 4>(ctx, a, 256);
-    case 35: return launch_gemm8_r<T, false, 5>(ctx, a, 256);
-    case 36: return launch_gemm8_r<T, false, 6>(ctx, a, 256);
-    case 37: return launch_gemm8_r<T, false, 7>(ctx, a, 256);
-    case 38: return launch_gemm8_r<T, false, 8>(ctx, a, 256);
-    case 39: return (a.epi & EPI_RES) ? launch_gemm8_r<T, true, 9>(ctx, a, 256) : launch_gemm8_r<T, false, 9>(ctx, a, 256);   // gemm8 without the stagger (correct results)
-#endif
   }
 #ifdef STAR_BENCH_VARIANTS
   if (tile >= 11 && tile <= 16 && tile != 14 && a.mode == A_PLAIN && !(a.epi & EPI_OUT_F32)) {   // ablation probes of the 256x256 main loop

@@ -271,7 +271,7 @@ STAR_DEV void barrier_keep_dma() {
 
 // workgroup barrier with NO wait at all in front of it (raw s_barrier): LDS-DMA and this wave's own ds_reads stay in flight
 // across it; the compiler still waits (lgkmcnt) before the first use of an LDS read's result.  Only for schedules whose
-// LDS hazards are covered by construction (gemm8.h).
+// LDS hazards are covered by construction (the epilogue staging of gemm.h).
 STAR_DEV void raw_barrier() {
 #ifdef STAR_HOSTEMU
   ::star_emu::block_sync();
