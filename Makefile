@@ -19,6 +19,7 @@ emu: tools/hostemu/libstar_emu.so
 # masked scores are finite (-1e30 / -30000), so NaNs can only come from NaN inputs and propagate either way
 build/hip/attn.o: HIPFLAGS += -fno-honor-nans -fno-slp-vectorize
 build/hip/attn7.o: HIPFLAGS += -fno-honor-nans -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form
+build/hip/gemm_as.o: HIPFLAGS += -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form
 build/hip/%.o: $(CSRC)/%.cpp $(wildcard $(CSRC)/*.h) include/star_hip.h
 	@mkdir -p build/hip
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
@@ -39,6 +40,7 @@ BENCH_OBJS := $(patsubst $(CSRC)/%.cpp,build/bench/%.o,$(SRCS))
 bench: tools/bench/libstar_hip_bench.so
 build/bench/attn.o: HIPFLAGS += -fno-honor-nans -fno-slp-vectorize
 build/bench/attn7.o: HIPFLAGS += -fno-honor-nans -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form
+build/bench/gemm_as.o: HIPFLAGS += -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form
 build/bench/%.o: $(CSRC)/%.cpp $(wildcard $(CSRC)/*.h) include/star_hip.h
 	@mkdir -p build/bench
 	$(HIPCC) $(HIPFLAGS) -DSTAR_BENCH_VARIANTS=1 -c $< -o $@

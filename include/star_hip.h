@@ -61,7 +61,10 @@ typedef struct star_gemm_desc {
   int32_t HW, F;                     /* temporal-conv geometry */
   int32_t up_crop;                   /* STAR_A_CONV3X3_UP: rows cropped top+bottom after the 2x upsample (1 UNet, 0 VAE) */
   int32_t epi;                       /* STAR_EPI_* */
-  int32_t force_tile;                /* 0 = auto; 1 256x256, 2 256x320, 3 128x128, 4 256x128, 9 2 x (128x256); anything else: bench build only */
+  int32_t force_tile;                /* 0 = auto; 1 256x256, 2 256x320, 3 128x128, 4 256x128, 9 2 x (128x256), 30 the A-stationary K = 320 kernel
+                                        (gemm_as.h: plain A, STAR_EPI_ROWAFF layers); anything else: bench build only */
+  const float* rowab;                /* STAR_EPI_ROWAFF (a LayerNorm folded into this projection, unet_v2v.py:448-450 + the Linear behind it): */
+  const float* colsum;               /*   out = a_m * acc + b_m * colsum[n] + bias[n], (a_m, b_m) = rowab[m] fp32 pairs, colsum fp32 [N]; else null */
 } star_gemm_desc;
 /* replaces: nn.Linear / nn.Conv2d / nn.Conv3d(3,1,1) / nn.Conv1d(k=1) call sites
  * (unet_v2v.py:151-155,274,294,500,526,553,612,639,648,717,1005,1025,1209-1220) */

@@ -123,7 +123,7 @@ int star_gemm(star_ctx* h, const star_gemm_desc* d) {
   a.M = d->M; a.N = d->N; a.K = d->K; a.lda = d->lda; a.ldc = d->ldc; a.ldr = d->ldr;
   a.mode = d->mode; a.H = d->H; a.Wd = d->Wd; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo;
   a.stride = d->stride; a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.HW = d->HW; a.F = d->F; a.up_crop = d->up_crop;
-  a.epi = d->epi; a.force_tile = d->force_tile;
+  a.epi = d->epi; a.force_tile = d->force_tile; a.rowab = d->rowab; a.colsum = d->colsum;
   return finish(h, op_gemm(&h->c, a));
 }
 

@@ -26,10 +26,6 @@ namespace star {
 
 #include "attn7_sched.inc"   // V7_SCHED_PK / V7_SCHED_F32: which vector instructions ride in the shadow of which MFMA
 
-template <class F, int... Is>
-STAR_DEV void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
-template <int N, class F>
-STAR_DEV void static_for(F&& f) { static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{}); }
 
 // ABL (timing ablations, wrong results by construction): 1 exp -> plain multiply, 2 no fragment refills, 4 no barrier / LDS-DMA, 8 no softmax VALU
 template <class T, int NQ, int PKSUM, int ABL = 0>

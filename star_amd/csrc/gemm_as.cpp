@@ -1,0 +1,44 @@
+// gemm_as.cpp -- launcher of gemm_astat_kernel (gemm_as.h); its own translation unit because it is built with
+// -mllvm -amdgpu-mfma-vgpr-form (Makefile): one wave per SIMD has a 512-register budget, the A panel lives in AGPRs and the
+// accumulators must stay in architectural VGPRs.
+#include "ops.h"
+#include "gemm_as.h"
+
+namespace star {
+
+// what the kernel can compute at all ...
+static bool covered(const GemmArgs& a) {
+  return a.mode == A_PLAIN && a.K == 320 && a.N % 64 == 0 && a.N <= 4096 && (a.epi & EPI_ROWAFF) && (a.epi & EPI_BIAS) &&
+         !(a.epi & (EPI_RES | EPI_OUT_F32 | EPI_GELU_TANH)) && a.rowab && a.colsum && a.bias && a.lda % 8 == 0 && a.ldc % 8 == 0;
+}
+// ... and where it is the automatic choice: wide outputs on many rows (the level-0 q | k | v and GEGLU projections)
+bool gemm_astat_applies(const GemmArgs& a) { return covered(a) && a.N >= 640 && a.M >= 65536; }
+
+template <class T>
+static int launch_astat(Ctx* ctx, const GemmArgs& a) {
+  GemmParams p{};
+  p.A = a.A; p.W = a.W; p.C = a.C; p.bias = a.bias; p.M = a.M; p.N = a.N; p.K = a.K; p.lda = a.lda; p.ldc = a.ldc; p.epi = a.epi;
+  p.rowab = a.rowab; p.colsum = a.colsum;
+  const size_t smem = 2 * (size_t)40960 + 4 * (size_t)8192 + 2 * (size_t)a.N * sizeof(float);   // W ring, per-wave staging blocks, bias + colsum
+  const dim3 grid((unsigned)((a.M + 255) / 256)), block(256);
+#ifdef STAR_BENCH_VARIANTS   // timing ablations (wrong results): no epilogue / no W staging / W fragments not re-read
+  if (a.force_tile == 31) { STAR_LAUNCH((gemm_astat_kernel<T, 0, 1>), grid, block, smem, ctx->stream, p); return 0; }
+  if (a.force_tile == 32) { STAR_LAUNCH((gemm_astat_kernel<T, 0, 2>), grid, block, smem, ctx->stream, p); return 0; }
+  if (a.force_tile == 33) { STAR_LAUNCH((gemm_astat_kernel<T, 0, 3>), grid, block, smem, ctx->stream, p); return 0; }
+#else
+  if (a.force_tile > 30) return ctx->fail("gemm (A-stationary): ablation ids exist only in the bench build");
+#endif
+  if (a.epi & EPI_GEGLU) STAR_LAUNCH((gemm_astat_kernel<T, 1>), grid, block, smem, ctx->stream, p);
+  else STAR_LAUNCH((gemm_astat_kernel<T, 0>), grid, block, smem, ctx->stream, p);
+  return 0;
+}
+
+int launch_gemm_astat(Ctx* ctx, const GemmArgs& a) {
+  if (!covered(a)) return ctx->fail("gemm (A-stationary): K = 320 plain-A layers with the folded-LayerNorm epilogue only");
+  if ((size_t)(a.M < 256 ? a.M : 256) * a.ldc * 2 >= ((size_t)1 << 32)) return ctx->fail("gemm (A-stationary): output rows too long for a 32-bit buffer range");
+  if (ctx->dtype == DT_F16) return launch_astat<f16>(ctx, a);
+  if (ctx->dtype == DT_BF16) return launch_astat<bf16>(ctx, a);
+  return ctx->fail("gemm (A-stationary): unsupported dtype");
+}
+
+}  // namespace star

@@ -8,6 +8,8 @@
 #pragma once
 #include <cstdint>
 #include <cstddef>
+#include <type_traits>
+#include <utility>
 
 #ifdef STAR_HOSTEMU
 #include "hostemu.h"
@@ -298,6 +300,17 @@ STAR_DEV void wave_lds_fence() {
 #else
 #define STAR_WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)
 #endif
+// ordering point between DS operations of ONE wave that touch the same bytes from different lanes, where no wait is wanted: the
+// hardware executes a wave's DS operations in order, so on the device this only stops the compiler from reordering them; the
+// emulator (lanes are fibers) needs the rendezvous
+STAR_DEV void wave_lds_order() {
+#ifdef STAR_HOSTEMU
+  int v = 0;
+  (void)::star_emu::wave_exchange(&v, 4);
+#else
+  asm volatile("" ::: "memory");
+#endif
+}
 #ifdef STAR_HOSTEMU
 #define STAR_SETPRIO(n)
 #else
@@ -540,6 +553,12 @@ STAR_DEV uint64_t wave_ballot(bool pred) {
 #else
 #define STAR_AGPR_PIN(x) asm volatile("" : "+a"(x))
 #endif
+
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{})
+template <class F, int... Is>
+STAR_DEV void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F>
+STAR_DEV void static_for(F&& f) { static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{}); }
 
 STAR_DEV float wave_sum(float v) {
   for (int m = 32; m >= 1; m >>= 1) v += shfl_xor(v, m);

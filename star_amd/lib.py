@@ -18,7 +18,7 @@ DEFAULT_LIB = os.path.join(_HERE, "libstar_hip.so")
 
 F16, BF16, F32 = 0, 1, 2
 A_PLAIN, A_CONV3X3, A_CONV3X3_UP, A_TCONV3 = 0, 1, 2, 3
-EPI_BIAS, EPI_RES, EPI_GEGLU, EPI_OUT_F32, EPI_GELU_TANH = 1, 2, 4, 8, 16
+EPI_BIAS, EPI_RES, EPI_GEGLU, EPI_OUT_F32, EPI_GELU_TANH, EPI_ROWAFF = 1, 2, 4, 8, 16, 32
 
 _TORCH2STAR = {torch.float16: F16, torch.bfloat16: BF16, torch.float32: F32}
 _STAR2TORCH = {v: k for k, v in _TORCH2STAR.items()}
@@ -70,6 +70,7 @@ class GemmDesc(ctypes.Structure):
         ("pad_t", ctypes.c_int32), ("pad_l", ctypes.c_int32),
         ("HW", ctypes.c_int32), ("F", ctypes.c_int32), ("up_crop", ctypes.c_int32),
         ("epi", ctypes.c_int32), ("force_tile", ctypes.c_int32),
+        ("rowab", ctypes.c_void_p), ("colsum", ctypes.c_void_p),
     ]
 
 
@@ -211,7 +212,7 @@ class Context:
 
     # ------------------------------------------------------------------ kernels
     def gemm(self, A, W, bias=None, res=None, out=None, *, mode=A_PLAIN, M=None, conv=None, temporal=None,
-             geglu=False, out_f32=False, force_tile=0, up_crop=1, gelu_tanh=False):
+             geglu=False, out_f32=False, force_tile=0, up_crop=1, gelu_tanh=False, rowab=None, colsum=None):
         """out[M, N] = epilogue(A' @ W^T).  A: [rows, lda] activations (channels-last tokens);
         W: [N, K]; conv=(NB,H,Wd,Cin,Ho,Wo,stride,pad_t,pad_l); temporal=(F,HW,Cin)."""
         self._chk_tensor(A, self.dtype); self._chk_tensor(W, self.dtype)
@@ -242,6 +243,11 @@ class Context:
         d.ldr = res.stride(0) if res is not None else 0
         d.epi = (EPI_BIAS if bias is not None else 0) | (EPI_RES if res is not None else 0) | \
                 (EPI_GEGLU if geglu else 0) | (EPI_OUT_F32 if out_f32 else 0) | (EPI_GELU_TANH if gelu_tanh else 0)
+        if rowab is not None:        # a LayerNorm folded into this projection: out = a_m * acc + b_m * colsum[n] + bias[n]
+            self._chk_tensor(rowab, torch.float32); self._chk_tensor(colsum, torch.float32)
+            assert tuple(rowab.shape) == (M, 2) and colsum.numel() == N and bias is not None
+            d.rowab, d.colsum = rowab.data_ptr(), colsum.data_ptr()
+            d.epi |= EPI_ROWAFF
         d.force_tile = force_tile
         self._check(self.lib.gemm(self.h, ctypes.byref(d)), "gemm")
         return out

@@ -37,7 +37,7 @@ def dev(ctx, t):
     return t.to(ctx.torch_device)
 
 
-PRODUCT_TILES = (0, 1, 2, 3, 4, 9, 10)
+PRODUCT_TILES = (0, 1, 2, 3, 4, 9, 10, 30)
 
 
 _BENCH_CTX = {}
@@ -182,6 +182,31 @@ def test_temporal_conv(ctx, dtype, Fr, H, Wd, C):
     wp = w[:, :, :, 0, 0].permute(0, 2, 1).reshape(C, 3 * C).contiguous()
     out = ctx.gemm(dev(ctx, a), dev(ctx, wp), bias=dev(ctx, b), res=dev(ctx, res), mode=L.A_TCONV3, temporal=(Fr, H * Wd, C))
     assert_close(out, ref, dtype, what="tconv")
+
+
+@pytest.mark.parametrize("tile", [0, 30])
+@pytest.mark.parametrize("M,N,geglu", [(300, 128, False), (257, 192, True), (520, 960, False), (64, 2560, True)])
+def test_gemm_folded_layer_norm_rows(ctx, dtype, M, N, geglu, tile):
+    """STAR_EPI_ROWAFF: out = a_m * (x W^T) + b_m * colsum[n] + bias[n] (a LayerNorm folded into the projection behind it,
+    unet_v2v.py:448-450 + :151-155 / :500) on the tiled kernel (tile 0 = auto) and on the A-stationary K = 320 kernel of
+    gemm_as.h (tile 30: a wave's rows of A live in registers, W streams through LDS), plain and with the GEGLU epilogue, ragged
+    row tails."""
+    g = torch.Generator().manual_seed(M + N)
+    K = 320
+    x = torch.randn(M, K, generator=g).to(dtype)
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dtype)
+    b = torch.randn(N, generator=g)
+    rowab = torch.stack([torch.rand(M, generator=g) + 0.5, torch.randn(M, generator=g)], dim=1).contiguous()
+    colsum = W.float().sum(1).contiguous()
+    acc = x.float() @ W.float().t()
+    full = rowab[:, :1] * acc + rowab[:, 1:] * colsum[None] + b[None]
+    if geglu:    # rows interleaved in 32-row (value, gate) blocks
+        fv = full.reshape(M, N // 64, 2, 32)
+        ref = (fv[:, :, 0] * F.gelu(fv[:, :, 1])).reshape(M, N // 2)
+    else:
+        ref = full
+    out = ctx.gemm(dev(ctx, x), dev(ctx, W), bias=dev(ctx, b), geglu=geglu, rowab=dev(ctx, rowab), colsum=dev(ctx, colsum), force_tile=tile)
+    assert_close(out, ref, dtype, scale=6.0, what=f"gemm rowaff tile {tile}")
 
 
 def ref_attention(q, k, v, heads):
