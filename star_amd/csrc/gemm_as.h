@@ -37,51 +37,23 @@ gemm_astat_kernel(const GemmParams p) {
   const int N = p.N;
   const T* __restrict__ Ag = (const T*)p.A;
 
-  // ---- this lane's rows of A as MFMA B operands (a lane owns row rb*32 + lq of its wave's 64): af[rb][ks] = A[m][16 ks + 8 h2 ..].
-  // Read straight from global memory they are 40 row-per-lane 16-byte loads per lane (32 rows x 32 B per instruction) with nothing
-  // to hide behind: ~15 us of a workgroup's 53.  Instead the panel comes through the (still idle) W ring by LDS-DMA, 128 rows x
-  // 640 B = 80 KB per pass in the swizzled 128-byte-row slab layout, whole lines, and the fragments are ds_read_b128s.
+  // ---- this lane's rows of A as MFMA B operands (a lane owns row rb*32 + lq of its wave's 64): af[rb][ks] = A[m][16 ks + 8 h2 ..]
   vec<T, 8> af[2][KS];
   float ra[2], rbv[2];
 #pragma unroll
   for (int rb = 0; rb < 2; ++rb) {
     int m = m0 + rb * 32 + lq;
     if (m > p.M - 1) m = p.M - 1;
+    const T* row = Ag + (size_t)m * p.lda + h2 * 8;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) af[rb][ks] = *reinterpret_cast<const vec<T, 8>*>(row + ks * 16);
     const vec<float, 2> ab = *reinterpret_cast<const vec<float, 2>*>(p.rowab + 2 * (size_t)m);
     ra[rb] = ab[0]; rbv[rb] = ab[1];
-  }
-  glds_wait();                       // the rowab loads are in registers before the first hand-counted LDS-DMA
-#pragma unroll
-  for (int ps = 0; ps < 2; ++ps) {   // pass ps: rows [128 ps, 128 ps + 128) of the block = the rows of waves 2 ps and 2 ps + 1
-    const int base_row = mwg + ps * 128 < p.M - 1 ? mwg + ps * 128 : p.M - 1;   // (a pass wholly past M re-reads the last row)
-    const char* abase = (const char*)(Ag + (size_t)base_row * p.lda);   // wave-uniform
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int r = q * 32 + (tid >> 3);
-      int m = mwg + ps * 128 + r;
-      if (m > p.M - 1) m = p.M - 1;
-      const uint32_t ao = (uint32_t)((m - base_row) * p.lda + ((tid & 7) ^ ((r >> 1) & 7)) * 8) * 2u;
-#pragma unroll
-      for (int sl = 0; sl < K / 64; ++sl) glds16_su(abase + sl * 128, ao, smem + sl * 16384 + q * 4096 + wv * 1024);
-    }
-    glds_wait();
-    block_sync();
-    if ((wv >> 1) == ps) {
-      const int wl = wv & 1;
-#pragma unroll
-      for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          const int row = wl * 64 + rb * 32 + lq;
-          af[rb][ks] = *reinterpret_cast<const vec<T, 8>*>(smem + (ks >> 2) * 16384 + row * 128 + ((((2 * ks + h2) & 7) ^ ((lq >> 1) & 7)) << 4));
-        }
-    }
-    block_sync();                    // the ring is free again (pass 1 / the W tiles)
   }
 #pragma unroll
   for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) STAR_AGPR_PIN(af[rb][ks]);   // MFMA-only operands: the accumulator half of the register file
+    for (int ks = 0; ks < KS; ++ks) STAR_AGPR_PIN(af[rb][ks]);
   for (int n = tid; n < N; n += 256) { bias_lds[n] = p.bias[n]; bias_lds[N + n] = p.colsum[n]; }
 
   // ---- W staging: thread (ps, tid) copies chunk (tid & 7) ^ swizzle of tile row ps*32 + (tid >> 3), one 64-k slab per instruction
@@ -225,6 +197,7 @@ gemm_astat_kernel(const GemmParams p) {
     });
     if constexpr (FLUSH) { flush_store(t - 1, 6, 0, true); flush_store(t - 1, 7, 1, true); }
   };
+  glds_wait();                       // the A / rowab loads are in registers before the first hand-counted LDS-DMA
   block_sync();                      // bias / colsum slice visible
   stage(0, 0);
   tile(0, std::integral_constant<int, 0>{}, std::false_type{});     // nothing to drain yet
