@@ -25,6 +25,8 @@ static int launch_astat(Ctx* ctx, const GemmArgs& a) {
   if (a.force_tile == 31) { STAR_LAUNCH((gemm_astat_kernel<T, 0, 1>), grid, block, smem, ctx->stream, p); return 0; }
   if (a.force_tile == 32) { STAR_LAUNCH((gemm_astat_kernel<T, 0, 2>), grid, block, smem, ctx->stream, p); return 0; }
   if (a.force_tile == 33) { STAR_LAUNCH((gemm_astat_kernel<T, 0, 3>), grid, block, smem, ctx->stream, p); return 0; }
+  if (a.force_tile == 34) { STAR_LAUNCH((gemm_astat_kernel<T, 0, 4>), grid, block, smem, ctx->stream, p); return 0; }
+  if (a.force_tile == 35) { STAR_LAUNCH((gemm_astat_kernel<T, 0, 5>), grid, block, smem, ctx->stream, p); return 0; }
 #else
   if (a.force_tile > 30) return ctx->fail("gemm (A-stationary): ablation ids exist only in the bench build");
 #endif

@@ -20,7 +20,8 @@
 
 namespace star {
 
-// ABL (bench builds, timing only, wrong results): 1 no epilogue, 2 no W staging / barrier after tile 0, 3 W fragments not re-read
+// ABL (bench builds, timing only, wrong results): 1 no epilogue, 2 no W staging / barrier after tile 0, 3 W fragments not re-read,
+// 4 = 1 + 2 (the k loop alone: MFMAs + W fragment reads), 5 = 4 + 3 (MFMAs alone)
 template <class T, int GEGLU, int ABL = 0>
 STAR_GLOBAL void STAR_LAUNCH_BOUNDS(256, 1)
 gemm_astat_kernel(const GemmParams p) {
@@ -140,15 +141,15 @@ gemm_astat_kernel(const GemmParams p) {
 
   auto tile = [&](int t, auto slot_tag, auto drain_tag) STAR_ALWAYS_INLINE {
     constexpr int SL = decltype(slot_tag)::value;
-    constexpr bool DRAIN = decltype(drain_tag)::value && ABL != 1;   // compile time: the epilogue pieces must share basic blocks with the MFMAs
+    constexpr bool DRAIN = decltype(drain_tag)::value && ABL != 1 && ABL < 4;   // compile time: the epilogue pieces must share basic blocks with the MFMAs
     // does THIS tile's k loop carry the stores of a flush?  (tile t drains tile t - 1; GEGLU flushes once two tiles are staged)
     const bool prev_flushed = GEGLU ? (SL == 1 && t >= 3) : (t >= 2);   // ... and did the PREVIOUS tile's?
     // W tile t has landed (the only vector-memory operations issued after its DMA are the 8 stores of the previous tile's
     // flush, if it had one; vmcnt retires in order), and every wave is done reading the other slot
-    if (ABL != 2 || t == 0) {
-      if (prev_flushed && ABL != 1) STAR_WAIT_VMCNT_N(8); else STAR_WAIT_VMCNT(0);
+    if ((ABL != 2 && ABL < 4) || t == 0) {
+      if (prev_flushed && ABL != 1 && ABL < 4) STAR_WAIT_VMCNT_N(8); else STAR_WAIT_VMCNT(0);
       barrier_keep_dma();
-      if (t + 1 < nt && ABL != 2) stage(t + 1, SL ^ 1);
+      if (t + 1 < nt && ABL != 2 && ABL < 4) stage(t + 1, SL ^ 1);
     }
     {
       f32x16 zero;   // assigned as a WHOLE vector: element-wise zeroing gets SLP-packed into <2 x float> stores, which keep the
@@ -171,7 +172,7 @@ gemm_astat_kernel(const GemmParams p) {
     }
     static_for<KS>([&](auto kstag) STAR_ALWAYS_INLINE {
       constexpr int ks = decltype(kstag)::value;
-      if (ks + 1 < KS && (ABL != 3 || ks == 0)) {
+      if (ks + 1 < KS && ((ABL != 3 && ABL != 5) || ks == 0)) {
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
           wf[(ks + 1) & 1][cb] = *reinterpret_cast<const vec<T, 8>*>(wfa[SL][(ks + 1) & 3] + ((ks + 1) >> 2) * SLAB + cb * 4096);
@@ -208,7 +209,7 @@ gemm_astat_kernel(const GemmParams p) {
   }
   if (t < nt) { tile(t, std::integral_constant<int, 1>{}, std::true_type{}); ++t; }
   // ---- drain the last tile (its accumulators sit in set (nt - 1) & 1)
-  if constexpr (ABL != 1) {
+  if constexpr (ABL != 1 && ABL < 4) {
     static_for<NU>([&](auto u) STAR_ALWAYS_INLINE {
       epi_load(nt - 1, u);
       if ((nt - 1) & 1) epi_unit(std::integral_constant<int, 1>{}, u); else epi_unit(std::integral_constant<int, 0>{}, u);

@@ -22,7 +22,7 @@ for (M, N, geglu) in [(843264, 960, 0), (843264, 2560, 1), (843264, 640, 0), (11
     run["tiled"] = lambda: ctx.gemm(A, W, bias=b, geglu=bool(geglu), rowab=rowab, colsum=colsum, out=out)
     run["astat"] = lambda: ctx.gemm(A, W, bias=b, geglu=bool(geglu), rowab=rowab, colsum=colsum, out=out, force_tile=30)
     if not geglu and len(sys.argv) > 2:
-        for k, ft in (("no_epi", 31), ("no_dma", 32), ("no_lds", 33)):
+        for k, ft in (("no_epi", 31), ("no_dma", 32), ("no_lds", 33), ("kloop", 34), ("mfma", 35)):
             run[k] = lambda ft=ft: ctx.gemm(A, W, bias=b, rowab=rowab, colsum=colsum, out=out, force_tile=ft)
     o = {}
     for k, f in run.items():
