@@ -74,7 +74,7 @@ STAR_DEV float gelu_tanh(float x) {
   return x * fast_rcp(1.0f + fast_exp2(-2.8853900817779268f * u));
 }
 
-template <class T, int BM, int BN, int WM, int WN, int AMODE, int MINW, bool F32OUT, bool STAGGER, int ABL = 0, int PIPE = 0, int EPIF = 0>  // ABL: ablation probes (bench only); PIPE: ring slots of the pipelined loop (0 = 2-stage loop); EPIF: 16-bit epilogue flavour (bit 0 residual add, bit 1 GEGLU, bit 2 tanh-GELU, bit 3 row-affine = folded LayerNorm)
+template <class T, int BM, int BN, int WM, int WN, int AMODE, int MINW, bool F32OUT, bool STAGGER, int ABL = 0, int PIPE = 0, int EPIF = 0, int SCHED = 0>  // SCHED: hand-placed 2-stage loop for one wave per SIMD (4 waves x 128 x 128); ABL: ablation probes (bench only); PIPE: ring slots of the pipelined loop (0 = 2-stage loop); EPIF: 16-bit epilogue flavour (bit 0 residual add, bit 1 GEGLU, bit 2 tanh-GELU, bit 3 row-affine = folded LayerNorm)
 STAR_GLOBAL void STAR_LAUNCH_BOUNDS(WM * WN * 64, MINW)
 gemm_kernel(const GemmParams p) {
   constexpr int NT = WM * WN * 64;
@@ -210,38 +210,49 @@ gemm_kernel(const GemmParams p) {
 
   // LDS of the 2-stage loop: [A stage 0 | A stage 1 | W stage 0 | W stage 1] -- with the stage a compile-time constant of the
   // unrolled loop, every fragment read is (loop-invariant register) + (16-bit immediate)
-  auto stage = [&](int kt, int buf) {
-    char* abuf = smem + buf * A_STAGE;
-    char* wbuf = smem + 2 * A_STAGE + buf * W_STAGE;
-    int ky = 0, kx = 0;
-    if constexpr (AMODE == A_CONV3X3 || AMODE == A_CONV3X3_UP) { ky = tap / 3; kx = tap - ky * 3; }
+  // one K tile's copies as separately placeable pieces (the scheduled loop puts them between MFMAs): stage_pre() fixes the
+  // tile's uniform terms, stage_piece<J>() issues copy J (0..NA-1: A, NA..NA+NW-1: W), stage_post() advances (tap, c0)
+  int st_ky = 0, st_kx = 0, st_tap_off = 0;
+  uint32_t st_tap_bit = 1;
+  auto stage_pre = [&]() STAR_ALWAYS_INLINE {
+    if constexpr (AMODE == A_CONV3X3 || AMODE == A_CONV3X3_UP) { st_ky = tap / 3; st_kx = tap - st_ky * 3; }
     // uniform byte offset of this K tile's (tap, channel block) from a lane's tap-0 source
-    int tap_off = 0;
-    if constexpr (AMODE == A_TCONV3) { tap_off = c0 * 2; g_rsrc = make_rsrc(g_base + (size_t)tap * p.HW * p.lda * 2, GLDS_BUF_RANGE); }
-    if constexpr (AMODE == A_CONV3X3) tap_off = ((ky * p.Wd + kx) * p.lda + c0) * 2;
-    const uint32_t tap_bit = 1u << tap;
-#pragma unroll
-    for (int j = 0; j < NA; ++j) {
+    if constexpr (AMODE == A_TCONV3) { st_tap_off = c0 * 2; g_rsrc = make_rsrc(g_base + (size_t)tap * p.HW * p.lda * 2, GLDS_BUF_RANGE); }
+    if constexpr (AMODE == A_CONV3X3) st_tap_off = ((st_ky * p.Wd + st_kx) * p.lda + c0) * 2;
+    st_tap_bit = 1u << tap;
+  };
+  auto stage_piece = [&](int kt, int buf, auto jc) STAR_ALWAYS_INLINE {
+    constexpr int J = decltype(jc)::value;
+    if constexpr (J < NA) {
+      constexpr int j = J;
       // wave-uniform LDS base: chunk q = j*NT + tid -> byte q*16 ; wave base = (j*NT + wave*64)*16
-      char* dst = abuf + (size_t)(j * NT + wvu * 64) * 16;
+      char* dst = smem + buf * A_STAGE + (size_t)(j * NT + wvu * 64) * 16;
       if constexpr (AMODE == A_PLAIN) {
         glds16_su(a_tile + (size_t)kt * (BK * 2), a_off[j], dst);
       } else if constexpr (AMODE == A_TCONV3 || AMODE == A_CONV3X3) {
-        glds16_buf(g_rsrc, (g_mask[j] & tap_bit) ? (uint32_t)(g_off[j] + tap_off) : GLDS_BUF_OOB, dst);
+        glds16_buf(g_rsrc, (g_mask[j] & st_tap_bit) ? (uint32_t)(g_off[j] + st_tap_off) : GLDS_BUF_OOB, dst);
       } else {  // A_CONV3X3_UP: conv input U[y][x] = X[(y+crop)>>1][x>>1], U is (2H-2*crop) x (2Wd)
-        const int yu = a_y[j] + ky, xu = a_x[j] + kx;
+        const int yu = a_y[j] + st_ky, xu = a_x[j] + st_kx;
         const void* src = (yu >= 0 && yu < 2 * p.H - 2 * p.up_crop && xu >= 0 && xu < 2 * p.Wd)
                   ? (const void*)(a_ptr[j] + ((size_t)((yu + p.up_crop) >> 1) * p.Wd + (xu >> 1)) * p.lda + c0) : p.zero_page;
         glds16(src, dst);
       }
+    } else {
+      constexpr int j = J - NA;
+      glds16_su(w_tile + (size_t)kt * (BK * 2), w_off[j], smem + 2 * A_STAGE + buf * W_STAGE + (size_t)(j * NT + wvu * 64) * 16);
     }
-#pragma unroll
-    for (int j = 0; j < NW; ++j) glds16_su(w_tile + (size_t)kt * (BK * 2), w_off[j], wbuf + (size_t)(j * NT + wvu * 64) * 16);
-    // advance (tap, c0)
+  };
+  auto stage_post = [&]() STAR_ALWAYS_INLINE {
     if constexpr (AMODE != A_PLAIN) {
       c0 += BK;
       if (c0 >= p.Cin) { c0 = 0; ++tap; }
     }
+  };
+  // LDS of the 2-stage loop: [A stage 0 | A stage 1 | W stage 0 | W stage 1]
+  auto stage = [&](int kt, int buf) {
+    stage_pre();
+    static_for<NA + NW>([&](auto jc) STAR_ALWAYS_INLINE { stage_piece(kt, buf, jc); });
+    stage_post();
   };
 
   f32x16 acc[TM][TN];
@@ -405,6 +416,91 @@ gemm_kernel(const GemmParams p) {
       if constexpr (PIPE > 2) { if (st < nsteps) { pstep(st, std::integral_constant<int, 1 % PIPE>{}); ++st; } }
       if constexpr (PIPE > 3) { if (st < nsteps) { pstep(st, std::integral_constant<int, 2 % PIPE>{}); ++st; } }
     }
+  } else if constexpr (SCHED != 0) {
+  // ---- one wave per SIMD, 128 x 128 per wave (TM = TN = 4, 256 accumulator registers): a third fewer LDS fragment bytes per MFMA
+  // than the 8-wave tiles.  Nothing hides a stall of the one wave, so every LDS read and every LDS-DMA has a fixed place between
+  // the MFMAs of the phase BEFORE the one that needs it (fences keep hipcc from moving them).  K tile kt (64 k, stage kt & 1) =
+  // four phases of 16 MFMAs (one 16-k step each, fragments double-buffered); the 8 fragment reads of the next phase sit in the
+  // first 8 MFMA gaps.  One barrier per tile, behind phase 2: every wave has read stage kt & 1 out (phase 3's fragments are in
+  // registers) and tile kt+1 has landed.  Tile kt+2's copies go into the stage just read out: the A pieces in the last 8 gaps of
+  // phase 3, the W pieces in the last 8 gaps of the next tile's phase 0 -- 1.5 to 2 tile times before they are waited for.
+  // The pieces are whole 128-byte lines (8 rows per wave-instruction), as in the 8-wave loop: the 32-deep ring slots of the
+  // pipelined loop above ask the L2 for every line twice (TCP_TCC_READ_REQ 134 M against 67 M at 8192^3, profiles/r03_gemm_sched_pmc.txt).
+  static_assert(PIPE == 0 && TM == 4 && TN == 4 && NT == 256 && NA == 8 && NW == 8 && !STAGGER, "the scheduled loop is built for 4 waves x (128 x 128)");
+  const char* afb[4];
+  const char* wfb[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const int sw = ((ks * 2 + fhalf) ^ ((frow >> 1) & 7)) << 4;
+    afb[ks] = opaque(smem + (wm * WTM + frow) * 128 + sw);
+    wfb[ks] = opaque(smem + 2 * A_STAGE + (wn * WTN + frow) * 128 + sw);
+  }
+  vec<T, 8> fa[2][4], fw[2][4];
+  auto frag_read = [&](auto cks, int sa, int swo, auto ci, auto cb) STAR_ALWAYS_INLINE {   // read #ci (0-3: A blocks, 4-7: W blocks) of 16-k step cks into buffer cb
+    constexpr int KS = decltype(cks)::value, I = decltype(ci)::value, Bf = decltype(cb)::value;
+    if constexpr (I < 4) fa[Bf][I] = *reinterpret_cast<const vec<T, 8>*>(afb[KS] + sa + I * 4096);
+    else fw[Bf][I - 4] = *reinterpret_cast<const vec<T, 8>*>(wfb[KS] + swo + (I - 4) * 4096);
+  };
+  auto phase = [&](auto cb, auto body) STAR_ALWAYS_INLINE {
+    constexpr int Bf = decltype(cb)::value;
+    static_for<16>([&](auto q) STAR_ALWAYS_INLINE {
+      constexpr int Q = decltype(q)::value;
+      constexpr int i = Q >> 2, j = (i & 1) ? 3 - (Q & 3) : (Q & 3);   // serpentine: consecutive MFMAs share one operand
+      acc[i][j] = mfma32<T>(fw[Bf][j], fa[Bf][i], acc[i][j]);
+      body(q);
+      STAR_SCHED_FENCE();
+    });
+  };
+  using B0 = std::integral_constant<int, 0>;
+  using B1 = std::integral_constant<int, 1>;
+  stage(0, 0);
+  if (nk > 1) { stage(1, 1); STAR_WAIT_VMCNT_N(NA + NW); } else { STAR_WAIT_VMCNT(0); }
+  barrier_keep_dma();
+  static_for<8>([&](auto c) STAR_ALWAYS_INLINE { frag_read(B0{}, 0, 0, c, B0{}); });
+  STAR_SCHED_FENCE();
+  int sa = 0, swo = 0;                    // byte offsets of the stage tile kt is read from
+  // STEADY: both copy groups are due; otherwise (first tile, last two) they are runtime-conditional
+  // memory operations of a phase: the fragment reads in the even MFMA gaps, the copies (phases 3 and 0) in the odd ones.  Read
+  // order W0 A0 W1 W2 W3 A1 A2 A3 = the order the next phase's MFMAs first need them.
+  auto rd = [&](auto cks, auto q, auto cb) STAR_ALWAYS_INLINE {
+    constexpr int Q = decltype(q)::value;
+    if constexpr ((Q & 1) == 0) {
+      constexpr int R = Q >> 1;
+      constexpr int I = R == 0 ? 4 : R == 1 ? 0 : R == 2 ? 5 : R == 3 ? 6 : R == 4 ? 7 : R - 4;
+      frag_read(cks, sa, swo, std::integral_constant<int, I>{}, cb);
+    }
+  };
+  auto tile = [&](int kt, auto steady) STAR_ALWAYS_INLINE {
+    constexpr bool STEADY = decltype(steady)::value;
+    const bool iw = STEADY || (kt >= 1 && kt + 1 < nk), ia = STEADY || kt + 2 < nk;
+    const int buf = kt & 1;
+    phase(B0{}, [&](auto q) STAR_ALWAYS_INLINE {
+      constexpr int Q = decltype(q)::value;
+      rd(B1{}, q, B1{});
+      if constexpr ((Q & 1) == 1 && ABL != 8 && ABL != 11) { if (iw) stage_piece(ABL == 9 ? 0 : kt + 1, buf ^ 1, std::integral_constant<int, (ABL == 9 ? NA : NA + (Q >> 1))>{}); }   // W pieces of tile kt+1
+      if constexpr (Q == 15 && ABL != 8) { if (iw) stage_post(); }
+    });
+    phase(B1{}, [&](auto q) STAR_ALWAYS_INLINE { rd(std::integral_constant<int, 2>{}, q, B0{}); });
+    phase(B0{}, [&](auto q) STAR_ALWAYS_INLINE {
+      constexpr int Q = decltype(q)::value;
+      rd(std::integral_constant<int, 3>{}, q, B1{});
+      if constexpr (Q == 14 && ABL != 10) { STAR_WAIT_VMCNT(0); }
+      if constexpr (Q == 15) barrier_keep_dma();
+    });
+    sa ^= A_STAGE; swo ^= W_STAGE;
+    phase(B1{}, [&](auto q) STAR_ALWAYS_INLINE {
+      constexpr int Q = decltype(q)::value;
+      if constexpr (Q == 0 && ABL != 8) { if (ia) stage_pre(); }
+      rd(B0{}, q, B0{});
+      if constexpr ((Q & 1) == 1 && ABL != 8) { if (ia) stage_piece(ABL == 9 ? 0 : kt + 2, buf, std::integral_constant<int, (ABL == 9 ? 0 : (Q >> 1))>{}); }   // A pieces of tile kt+2
+    });
+  };
+  {
+    int kt = 0;
+    if (nk > 0) { tile(0, std::false_type{}); kt = 1; }
+    for (; kt + 2 < nk; ++kt) tile(kt, std::true_type{});
+    for (; kt < nk; ++kt) tile(kt, std::false_type{});
+  }
   } else {
   // Staggered wave groups.  The two waves that share a SIMD (w and w+4) belong to this same workgroup and meet at the
   // same barrier every K tile; left alone they run in lockstep -- both issue the next tile's LDS-DMA + address VALU, both
@@ -575,7 +671,7 @@ gemm_kernel(const GemmParams p) {
         ra[i] = ab[0]; rb[i] = ab[1];
       }
     }
-    load_res(0);
+    if constexpr (SCHED == 0) load_res(0);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       // ---- registers -> LDS (T, row-major [32][out_wtn])
@@ -620,7 +716,9 @@ gemm_kernel(const GemmParams p) {
         }
       }
       barrier_keep_dma();
-      if (i + 1 < TM) load_res(i + 1);   // the next block's residual, ahead of this block's stores
+      // the next block's residual, ahead of this block's stores (the one-wave-per-SIMD tile has no registers for two blocks of it:
+      // it loads each block's residual just before use)
+      if constexpr (SCHED == 0) { if (i + 1 < TM) load_res(i + 1); } else load_res(i);
       // ---- LDS -> global: whole 16-B chunks along rows (+ residual, already in registers)
       store_block(i);
       barrier_keep_dma();

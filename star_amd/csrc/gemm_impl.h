@@ -1,6 +1,7 @@
 // gemm_impl.h -- tile selection + launch for gemm_kernel (see gemm.h), instantiated once per storage type in gemm_f16.cpp /
 // gemm_bf16.cpp (two translation units: gemm_kernel has ~100 instantiations per type and is the longest compile of the build).
 #pragma once
+#include <cstdlib>
 #include "ops.h"
 #include "gemm.h"
 
@@ -8,7 +9,7 @@ namespace star {
 
 // ALLEPI: also instantiate the tanh-GELU and folded-LayerNorm epilogue flavours (the auto-selected tiles 1-4 only: every
 // flavour is one more kernel per tile, mode and dtype, and these are the longest compiles of the build)
-template <class T, int BM, int BN, int WM, int WN, int MINW, bool F32OUT, bool STAGGER, int PIPE = 0, bool ALLEPI = false>
+template <class T, int BM, int BN, int WM, int WN, int MINW, bool F32OUT, bool STAGGER, int PIPE = 0, bool ALLEPI = false, int SCHED = 0, int ABLV = 0>
 static int launch_gemm_f(Ctx* ctx, const GemmArgs& a) {
   GemmParams p{};
   p.A = a.A; p.W = a.W; p.C = a.C; p.bias = a.bias; p.res = a.res; p.zero_page = ctx->zero_page;
@@ -34,7 +35,7 @@ static int launch_gemm_f(Ctx* ctx, const GemmArgs& a) {
   const bool rowaff = !F32OUT && (a.epi & EPI_ROWAFF);
   if (rowaff && (res || gelut || a.mode != A_PLAIN || !a.rowab || !a.colsum || !(a.epi & EPI_BIAS)))
     return ctx->fail("gemm: the folded-LayerNorm epilogue is for plain-A layers without a residual and needs rowab, colsum and bias");
-#define STAR_GEMM_GO(MODE, EF) STAR_LAUNCH((gemm_kernel<T, BM, BN, WM, WN, MODE, MINW, F32OUT, STAGGER, 0, PIPE, EF>), grid, block, smem, ctx->stream, p)
+#define STAR_GEMM_GO(MODE, EF) STAR_LAUNCH((gemm_kernel<T, BM, BN, WM, WN, MODE, MINW, F32OUT, STAGGER, ABLV, PIPE, EF, SCHED>), grid, block, smem, ctx->stream, p)
   switch (a.mode) {
     case A_PLAIN:
       if constexpr (F32OUT) STAR_GEMM_GO(A_PLAIN, 0);
@@ -52,7 +53,8 @@ static int launch_gemm_f(Ctx* ctx, const GemmArgs& a) {
       if constexpr (F32OUT) STAR_GEMM_GO(A_CONV3X3, 0); else { if (res) STAR_GEMM_GO(A_CONV3X3, 1); else STAR_GEMM_GO(A_CONV3X3, 0); }
       break;
     case A_CONV3X3_UP:
-      if constexpr (F32OUT) STAR_GEMM_GO(A_CONV3X3_UP, 0); else { if (res) STAR_GEMM_GO(A_CONV3X3_UP, 1); else STAR_GEMM_GO(A_CONV3X3_UP, 0); }
+      if constexpr (SCHED != 0) return ctx->fail("gemm: the scheduled tile has no nearest-x2 conv mode");
+      else if constexpr (F32OUT) STAR_GEMM_GO(A_CONV3X3_UP, 0); else { if (res) STAR_GEMM_GO(A_CONV3X3_UP, 1); else STAR_GEMM_GO(A_CONV3X3_UP, 0); }
       break;
     case A_TCONV3:
       if constexpr (F32OUT) STAR_GEMM_GO(A_TCONV3, 0); else { if (res) STAR_GEMM_GO(A_TCONV3, 1); else STAR_GEMM_GO(A_TCONV3, 0); }
@@ -80,7 +82,14 @@ static int launch_gemm(Ctx* ctx, const GemmArgs& a) {
   }
   if (!tile) {
     const bool geglu = (a.epi & EPI_GEGLU) != 0;
-    if (a.M <= 4096 && a.N <= 1024) tile = 3;                          // small problems: more, smaller tiles
+    // long-K gathered layers whose width is a multiple of 256 and that fill the chip at least twice (3x3 convs and temporal convs of
+    // the 1280-wide levels): the one-wave-per-SIMD tile, 4-7 % faster there and bit-identical (profiles/r03_gemm_sched_ab.txt);
+    // with fewer tiles the 256 x 320 tile's smaller tail wins, and plain-A layers of these shapes tie
+    const bool sched_ok = (a.mode == A_CONV3X3 || a.mode == A_TCONV3) && a.N % 256 == 0 && a.K >= 2560 &&
+                          !(a.epi & (EPI_OUT_F32 | EPI_ROWAFF | EPI_GELU_TANH | EPI_GEGLU)) &&
+                          (int64_t)((a.M + 255) / 256) * (a.N / 256) >= 512 && !std::getenv("STAR_NO_SCHED");
+    if (sched_ok) tile = 17;
+    else if (a.M <= 4096 && a.N <= 1024) tile = 3;                     // small problems: more, smaller tiles
     else if (!geglu && a.N % 320 == 0) tile = 2;                        // 320 / 640 / 960 / 1280 / 1920-wide layers
     // (rounds 1-2 sent the short-K GEGLU layers to tile 9, two 4-wave workgroups per CU hiding each other's GELU epilogue;
     // with the erfc-form GELU and the compile-time epilogue the 8-wave 256x256 tile is 7 % faster there: 1.89 vs 2.04 ms at
@@ -93,6 +102,10 @@ static int launch_gemm(Ctx* ctx, const GemmArgs& a) {
     // 4-wave variants of the same tiles on the K = 320 layers (profiles/r01_gemm_tile_sweep.txt)
     case 1: return launch_gemm_t<T, 256, 256, 4, 2, 2, false, 0, true>(ctx, a);
     case 2: return launch_gemm_t<T, 256, 320, 4, 2, 2, false, 0, true>(ctx, a);
+    // 4 waves x (128 x 128), one wave per SIMD, hand-placed 2-stage loop (gemm.h SCHED): plain / 3x3 conv / temporal conv, 16-bit output
+    case 17:
+      if (a.epi & (EPI_OUT_F32 | EPI_ROWAFF | EPI_GELU_TANH)) return ctx->fail("gemm: tile 17 has the plain / residual / GEGLU 16-bit epilogues only");
+      return launch_gemm_f<T, 256, 256, 2, 2, 1, false, false, 0, false, 1>(ctx, a);
     case 3: return launch_gemm_t<T, 128, 128, 2, 2, 2, false, 0, true>(ctx, a);
     case 4: return launch_gemm_t<T, 256, 128, 4, 1, 1, false, 0, true>(ctx, a);
 #ifdef STAR_BENCH_VARIANTS   // A/B experiments of round 1 / 2 that lost to the tiles above (profiles/r01_gemm_ablation.txt, r02_gemm8_ablation.txt)
@@ -100,7 +113,14 @@ static int launch_gemm(Ctx* ctx, const GemmArgs& a) {
     // (the 256x320 tile has no room for the carried fragments: 730+ VGPR spills when staggered)
     case 7: return launch_gemm_t<T, 256, 256, 4, 2, 2, false, 4>(ctx, a);   // pipelined main loop (ring of 4 x 32-k slots)
     case 8: return launch_gemm_t<T, 256, 320, 4, 2, 2, false, 4>(ctx, a);
-    case 14: return launch_gemm_t<T, 256, 256, 2, 2, 1>(ctx, a);   // 4 waves x (128 x 128), one wave per SIMD, accumulators in AGPRs: 1/3 fewer LDS fragment reads
+    case 14: return launch_gemm_t<T, 256, 256, 2, 2, 1>(ctx, a);
+    // timing ablations of tile 17 (garbage results): no DMA in the loop / every copy re-reads one 1 KB piece (L1 hits) / DMA never waited for / A pieces only
+    case 20: case 21: case 22: case 23:
+      if (a.mode != A_PLAIN || (a.epi & ~EPI_BIAS)) return ctx->fail("gemm: ablation tile");
+      if (tile == 20) return launch_gemm_f<T, 256, 256, 2, 2, 1, false, false, 0, false, 1, 8>(ctx, a);
+      if (tile == 21) return launch_gemm_f<T, 256, 256, 2, 2, 1, false, false, 0, false, 1, 9>(ctx, a);
+      if (tile == 22) return launch_gemm_f<T, 256, 256, 2, 2, 1, false, false, 0, false, 1, 10>(ctx, a);
+      return launch_gemm_f<T, 256, 256, 2, 2, 1, false, false, 0, false, 1, 11>(ctx, a);   // 4 waves x (128 x 128), one wave per SIMD, accumulators in AGPRs: 1/3 fewer LDS fragment reads
 #endif
     // two independent 4-wave workgroups per CU on a 128 x 320 tile (two 32-deep LDS slots, 56 KB each): one group's prologue /
     // epilogue / store drain runs beside the other's MFMAs -- for the short-K layers, whose tiles spend most of their time

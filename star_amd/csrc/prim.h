@@ -250,14 +250,8 @@ STAR_DEV void glds_wait() {
 #define STAR_WAIT_VMCNT_N(expr)                                                            \
   do {                                                                                     \
     constexpr int star_n_ = (expr);                                                        \
-    static_assert(star_n_ >= 0 && star_n_ <= 12, "vmcnt count out of the supported range"); \
-    if constexpr (star_n_ == 0) STAR_WAIT_VMCNT(0); else if constexpr (star_n_ == 1) STAR_WAIT_VMCNT(1);      \
-    else if constexpr (star_n_ == 2) STAR_WAIT_VMCNT(2); else if constexpr (star_n_ == 3) STAR_WAIT_VMCNT(3); \
-    else if constexpr (star_n_ == 4) STAR_WAIT_VMCNT(4); else if constexpr (star_n_ == 5) STAR_WAIT_VMCNT(5); \
-    else if constexpr (star_n_ == 6) STAR_WAIT_VMCNT(6); else if constexpr (star_n_ == 7) STAR_WAIT_VMCNT(7); \
-    else if constexpr (star_n_ == 8) STAR_WAIT_VMCNT(8); else if constexpr (star_n_ == 9) STAR_WAIT_VMCNT(9); \
-    else if constexpr (star_n_ == 10) STAR_WAIT_VMCNT(10); else if constexpr (star_n_ == 11) STAR_WAIT_VMCNT(11); \
-    else STAR_WAIT_VMCNT(12);                                                              \
+    static_assert(star_n_ >= 0 && star_n_ <= 63, "vmcnt count out of the counter's range"); \
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(star_n_) : "memory");                        \
   } while (0)
 #endif
 // workgroup barrier WITHOUT the vmcnt(0) drain that __syncthreads() implies while LDS-DMA is in flight: own LDS

@@ -37,7 +37,7 @@ def dev(ctx, t):
     return t.to(ctx.torch_device)
 
 
-PRODUCT_TILES = (0, 1, 2, 3, 4, 9, 10, 30)
+PRODUCT_TILES = (0, 1, 2, 3, 4, 9, 10, 17, 30)
 
 
 _BENCH_CTX = {}
@@ -182,6 +182,57 @@ def test_temporal_conv(ctx, dtype, Fr, H, Wd, C):
     wp = w[:, :, :, 0, 0].permute(0, 2, 1).reshape(C, 3 * C).contiguous()
     out = ctx.gemm(dev(ctx, a), dev(ctx, wp), bias=dev(ctx, b), res=dev(ctx, res), mode=L.A_TCONV3, temporal=(Fr, H * Wd, C))
     assert_close(out, ref, dtype, what="tconv")
+
+
+@pytest.mark.parametrize("M,N,K", [(515, 512, 256), (300, 264, 64), (257, 256, 448), (130, 1280, 128)])
+def test_gemm_scheduled_tile(ctx, dtype, M, N, K):
+    """tile 17 (4 waves x 128 x 128, one wave per SIMD, hand-placed 2-stage loop): bias / residual / GEGLU epilogues against fp32,
+    and bit-for-bit against the 8-wave tile (both add the k-steps of an output in the same order); odd tile counts exercise the
+    first-tile / last-two-tiles paths of the loop.  The tile has no fp32-output flavour: refused."""
+    g = torch.Generator().manual_seed(M + 3 * N + K)
+    A = torch.randn(M, K, generator=g).to(dtype)
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dtype)
+    b = torch.randn(N, generator=g)
+    R = torch.randn(M, N, generator=g).to(dtype)
+    Ad, Wd_, bd, Rd = dev(ctx, A), dev(ctx, W), dev(ctx, b), dev(ctx, R)
+    out = ctx.gemm(Ad, Wd_, bias=bd, res=Rd, force_tile=17)
+    assert_close(out, A.float() @ W.float().T + b + R.float(), dtype, what="gemm tile 17 +res")
+    assert torch.equal(out, ctx.gemm(Ad, Wd_, bias=bd, res=Rd, force_tile=1))
+    out = ctx.gemm(Ad, Wd_, bias=bd, force_tile=17)
+    assert torch.equal(out, ctx.gemm(Ad, Wd_, bias=bd, force_tile=1))
+    if N % 64 == 0:
+        out = ctx.gemm(Ad, Wd_, bias=bd, geglu=True, force_tile=17)
+        assert torch.equal(out, ctx.gemm(Ad, Wd_, bias=bd, geglu=True, force_tile=1))
+    with pytest.raises(L.StarError):
+        ctx.gemm(Ad, Wd_, out_f32=True, force_tile=17)
+
+
+@pytest.mark.parametrize("NB,Cin,H,Wd,Cout", [(2, 64, 10, 8, 96), (1, 128, 18, 16, 256), (3, 320, 10, 8, 320)])
+def test_conv_scheduled_tile(ctx, dtype, NB, Cin, H, Wd, Cout):
+    """the gathered modes of tile 17 (3x3 conv stride 1 and 2, temporal conv + residual) against torch and bit-for-bit against the auto tile"""
+    g = torch.Generator().manual_seed(Cin + H + 1)
+    x = torch.randn(NB, Cin, H, Wd, generator=g).to(dtype)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)).to(dtype)
+    b = torch.randn(Cout, generator=g)
+    wp = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous()
+    xr, wpd, bd = dev(ctx, nhwc_rows(x)), dev(ctx, wp), dev(ctx, b)
+    ref = F.conv2d(x.float(), w.float(), b, padding=1)
+    out = ctx.gemm(xr, wpd, bias=bd, mode=L.A_CONV3X3, conv=(NB, H, Wd, Cin, H, Wd, 1, 1, 1), force_tile=17)
+    assert_close(out, nhwc_rows(ref), dtype, what="conv3x3 s1 tile 17")
+    assert torch.equal(out, ctx.gemm(xr, wpd, bias=bd, mode=L.A_CONV3X3, conv=(NB, H, Wd, Cin, H, Wd, 1, 1, 1)))
+    ref = F.conv2d(x.float(), w.float(), b, stride=2, padding=(2, 1))
+    Ho, Wo = ref.shape[2:]
+    out = ctx.gemm(xr, wpd, bias=bd, mode=L.A_CONV3X3, conv=(NB, H, Wd, Cin, Ho, Wo, 2, 2, 1), force_tile=17)
+    assert_close(out, nhwc_rows(ref), dtype, what="conv3x3 s2 tile 17")
+    with pytest.raises(L.StarError):      # no nearest-x2 mode in this tile
+        ctx.gemm(xr, wpd, bias=bd, mode=L.A_CONV3X3_UP, conv=(NB, H, Wd, Cin, 2 * H - 2, 2 * Wd, 1, 1, 1), force_tile=17)
+    # temporal conv: NB frames of H x Wd, Cin channels
+    if Cin == Cout:
+        wt = (torch.randn(Cin, 3 * Cin, generator=g) / math.sqrt(3 * Cin)).to(dtype)
+        a = nhwc_rows(x)
+        ad, wtd = dev(ctx, a), dev(ctx, wt)
+        o17 = ctx.gemm(ad, wtd, bias=bd, res=ad, mode=L.A_TCONV3, temporal=(NB, H * Wd, Cin), force_tile=17)
+        assert torch.equal(o17, ctx.gemm(ad, wtd, bias=bd, res=ad, mode=L.A_TCONV3, temporal=(NB, H * Wd, Cin)))
 
 
 @pytest.mark.parametrize("tile", [0, 30])

@@ -1,6 +1,6 @@
 """Run one workload in a loop for a few seconds while sampling socket power / shader clock of GPU 0 from sysfs hwmon twice a
 second (never run rocm-smi beside a kernel on this pool: it faulted every run, profiles/r03_attn7_ab.txt).
-   python tools/power_loop.py gemm M N K [res]     |  attn VARIANT  |  forward [frames h w]"""
+   python tools/power_loop.py gemm M N K [tile | vendor]     |  attn VARIANT  |  forward [frames h w]"""
 import glob, os, sys, threading, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -29,8 +29,8 @@ if kind == "gemm":
     ctx = L.Context(0, dt)
     A = torch.randn(M, K, device="cuda", dtype=dt); W = torch.randn(N, K, device="cuda", dtype=dt) * 0.05
     out = torch.empty(M, N, device="cuda", dtype=dt)
-    res = torch.randn(M, N, device="cuda", dtype=dt) if len(sys.argv) > 5 else None
-    fn = lambda: ctx.gemm(A, W, out=out, res=res)
+    tile = sys.argv[5] if len(sys.argv) > 5 else "0"
+    fn = (lambda: torch.matmul(A, W.t(), out=out)) if tile == "vendor" else (lambda: ctx.gemm(A, W, out=out, force_tile=int(tile)))
     work = 2.0 * M * N * K
 elif kind == "attn":
     ctx = L.Context(0, dt)
