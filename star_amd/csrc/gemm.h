@@ -725,6 +725,7 @@ gemm_kernel(const GemmParams p) {
     }
   }
   if constexpr (F32OUT) block_sync();   // the next tile's LDS-DMA must not overtake this tile's last fragment reads
+  if constexpr (SCHED != 0) break;      // the one-wave-per-SIMD tile is launched one workgroup per output tile: a visibly single trip keeps the workitem id out of scratch
   }   // persistent tile walk
 }
 

@@ -26,7 +26,7 @@ static int launch_gemm_f(Ctx* ctx, const GemmArgs& a) {
   static_assert(smem_epi <= smem_loop, "the epilogue's staging blocks must fit under the bias slice");
   constexpr size_t smem = smem_loop + 2 * (size_t)BN * sizeof(float);   // + this tile's bias slice (+ column sums of a folded LayerNorm)
   unsigned nwg = (unsigned)(p.tiles_m * p.tiles_n);
-  if (a.persist > 0 && nwg > (unsigned)a.persist) nwg = (unsigned)a.persist;   // persistent tile walk (gemm.h)
+  if (SCHED == 0 && a.persist > 0 && nwg > (unsigned)a.persist) nwg = (unsigned)a.persist;   // persistent tile walk (gemm.h)
   dim3 grid(nwg), block(WM * WN * 64);
   // 16-bit epilogue flavour (compile-time in the kernel): plain / + residual / GEGLU (plain-A layers only, no residual)
   const bool res = !F32OUT && (a.epi & EPI_RES), geglu = !F32OUT && (a.epi & EPI_GEGLU), gelut = !F32OUT && (a.epi & EPI_GELU_TANH);
@@ -46,7 +46,8 @@ static int launch_gemm_f(Ctx* ctx, const GemmArgs& a) {
             else STAR_GEMM_GO(A_PLAIN, 4);
           } else return ctx->fail("gemm: this tile has no tanh-GELU / folded-LayerNorm epilogue (tiles 1-4 do)");
         }
-        else if (geglu) STAR_GEMM_GO(A_PLAIN, 2); else if (res) STAR_GEMM_GO(A_PLAIN, 1); else STAR_GEMM_GO(A_PLAIN, 0);
+        else if (geglu) { if constexpr (SCHED != 0) return ctx->fail("gemm: no GEGLU flavour of the scheduled tile"); else STAR_GEMM_GO(A_PLAIN, 2); }
+        else if (res) STAR_GEMM_GO(A_PLAIN, 1); else STAR_GEMM_GO(A_PLAIN, 0);
       }
       break;
     case A_CONV3X3:
@@ -104,7 +105,7 @@ static int launch_gemm(Ctx* ctx, const GemmArgs& a) {
     case 2: return launch_gemm_t<T, 256, 320, 4, 2, 2, false, 0, true>(ctx, a);
     // 4 waves x (128 x 128), one wave per SIMD, hand-placed 2-stage loop (gemm.h SCHED): plain / 3x3 conv / temporal conv, 16-bit output
     case 17:
-      if (a.epi & (EPI_OUT_F32 | EPI_ROWAFF | EPI_GELU_TANH)) return ctx->fail("gemm: tile 17 has the plain / residual / GEGLU 16-bit epilogues only");
+      if (a.epi & (EPI_OUT_F32 | EPI_ROWAFF | EPI_GELU_TANH | EPI_GEGLU)) return ctx->fail("gemm: tile 17 has the plain and residual 16-bit epilogues only");
       return launch_gemm_f<T, 256, 256, 2, 2, 1, false, false, 0, false, 1>(ctx, a);
     case 3: return launch_gemm_t<T, 128, 128, 2, 2, 2, false, 0, true>(ctx, a);
     case 4: return launch_gemm_t<T, 256, 128, 4, 1, 1, false, 0, true>(ctx, a);
