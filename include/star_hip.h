@@ -137,6 +137,12 @@ int star_unet_forward(star_ctx* ctx, const float* xt, int64_t t, const float* y,
  * self-attention of each net's first spatial transformer) is computed once. */
 int star_unet_forward_cfg(star_ctx* ctx, const float* xt, int64_t t, const float* y_cond, const float* y_uncond,
                           const float* hint, float* out_cond, float* out_uncond, int32_t f, int32_t h, int32_t w);
+/* Replay the UNet forward from a captured hipGraph (off by default).  A forward is a fixed sequence of ~4700 kernel launches that
+ * depends on (guidance branches, f, h, w) only; with enable != 0 the first forward of a shape runs as usual (it sizes the activation
+ * pool), the second is captured on a stream the context owns, later ones copy xt / y / hint into the graph's staging buffers, refresh
+ * the timestep row and issue one hipGraphLaunch, ordered against the context's stream with events.  Results are bit-identical to the
+ * eager path.  A trimmed pool (star_pool_trim, or an allocation that had to drop the cache) invalidates the graph; it is re-captured. */
+int star_unet_graph(star_ctx* ctx, int32_t enable);
 /* replaces: VideoControlNet.forward (unet_v2v.py:2134-2206) on its own -- the 13 residuals ControlledV2VUNet.forward adds to the skip
  * connections and the middle block (:1746-1748, 1790-1800): residuals[i] receives channels-last rows [f * H_i * W_i, C_i] in the
  * context's storage dtype, i = 0..11 the zero-conv'd encoder outputs (level sizes (H, W) -> (H/2 + 1, W/2) per Downsample), 12 the

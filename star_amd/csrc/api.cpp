@@ -218,6 +218,11 @@ int star_unet_forward_cfg(star_ctx* h, const float* xt, int64_t t, const float* 
   float* outs[2] = {out_cond, out_uncond};
   return finish(h, unet_forward_n(&h->c, xt, (long long)t, ys, hint, outs, 2, f, hh, w));
 }
+int star_unet_graph(star_ctx* h, int32_t enable) {
+  if (!h) return 1;
+  h->c.unet_graph = enable != 0;
+  return 0;
+}
 int star_controlnet_forward(star_ctx* h, const float* xt, int64_t t, const float* y, const float* hint, void* const* residuals,
                             int32_t n_residuals, int32_t f, int32_t hh, int32_t w) {
   if (h) rt::set_device(h->c.device);

@@ -50,6 +50,7 @@ class Pool {
     live_.erase(it);
   }
   void trim() {
+    ++gen_;   // cached blocks go back to the driver: captured graphs that hold their addresses are stale
     for (auto& kv : free_) { rt::dev_free(kv.second); total_ -= kv.first; bytes_of_.erase(kv.second); }
     free_.clear();
   }
@@ -62,7 +63,9 @@ class Pool {
   }
   size_t total() const { return total_; }
   size_t peak() const { return peak_; }
+  uint64_t generation() const { return gen_; }
  private:
+  uint64_t gen_ = 0;
   std::multimap<size_t, void*> free_;
   std::unordered_map<void*, size_t> live_, bytes_of_;
   size_t total_ = 0, in_use_ = 0, peak_ = 0;
@@ -110,6 +113,7 @@ struct Ctx {
   std::shared_ptr<VaeModel> vae;
   bool profiling = false;
   std::vector<ProfRec> prof;
+  bool unet_graph = false;   // star_unet_graph(): replay the UNet forward from a captured hipGraph (unet.cpp)
   int fail(const std::string& m) { err = m; return 1; }
   size_t esize() const { return dtype == DT_F32 ? 4 : 2; }
 };

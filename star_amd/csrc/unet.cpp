@@ -11,7 +11,15 @@
 
 namespace star {
 
-UNetModel::~UNetModel() { for (void* p : owned) rt::dev_free(p); }
+UNetModel::~UNetModel() {
+  for (auto& kv : graphs) {
+    UNetGraph& g = kv.second;
+    rt::graph_destroy(g.exec);
+    for (float* p : {g.xt, g.hint, g.y[0], g.y[1], g.out[0], g.out[1], g.tsin}) if (p) rt::dev_free(p);
+  }
+  rt::stream_destroy(gstream);
+  for (void* p : owned) rt::dev_free(p);
+}
 
 // ------------------------------------------------------------------ weight staging / repacking
 namespace {
@@ -385,20 +393,69 @@ int unet_build(Ctx* ctx, const UNetCfg& cfg) {
   return 0;
 }
 
-static int time_embedding(Ctx* ctx, const Net& net, long long t, int dim, int E, Buf& tmp_in, Buf& tmp_mid, float* out) {
-  std::vector<float> se;
-  host_sinusoidal(t, dim, se);
-  rt::memcpy_h2d(tmp_in.p, se.data(), (size_t)dim * 4, ctx->stream);
-  rt::stream_sync(ctx->stream);  // `se` is a stack temporary
-  if (op_gemv(ctx, tmp_in.as<float>(), net.time0.w.p, (const float*)net.time0.b.p, tmp_mid.as<float>(), E, dim, false, true)) return 1;
+// the timestep MLP on the sinusoidal row `tsin` (device, fp32 [dim]; written by the caller: the only host-computed input of a forward)
+static int time_embedding(Ctx* ctx, const Net& net, const float* tsin, int dim, int E, Buf& tmp_mid, float* out) {
+  if (op_gemv(ctx, tsin, net.time0.w.p, (const float*)net.time0.b.p, tmp_mid.as<float>(), E, dim, false, true)) return 1;
   return op_gemv(ctx, tmp_mid.as<float>(), net.time2.w.p, (const float*)net.time2.b.p, out, E, E, false, false);
+}
+
+static int unet_forward_impl(Ctx* ctx, const float* xt, const float* tsin, const float* const* ys, const float* hint, float* const* outs, int nb,
+                             int F, int H, int W, void* const* control_tap, int n_tap);
+
+// One forward = a fixed sequence of ~4700 kernel launches that depends on (branches, frames, latent size) only.  With
+// star_unet_graph(ctx, 1) the second forward of a shape is captured into a hipGraph and later ones replay it: the caller's tensors
+// are copied into the staging buffers the graph was captured with, the sinusoidal row is refreshed, one hipGraphLaunch replaces
+// the launches.  The first forward of a shape always runs eagerly: it sizes the activation pool and sets the kernels' LDS
+// attributes, neither of which may happen under capture.
+static int unet_forward_graph(Ctx* ctx, UNetModel& M, const float* xt, long long t, const float* const* ys, const float* hint,
+                              float* const* outs, int nb, int F, int H, int W, bool* ran) {
+  *ran = false;
+  const UNetCfg& cfg = M.cfg;
+  UNetGraph& g = M.graphs[{nb, F, H, W}];
+  if (g.captured && g.pool_gen != ctx->pool.generation()) { rt::graph_destroy(g.exec); g.captured = false; g.n_x = 0; }   // trimmed pool: the eager path re-warms it
+  if (g.n_x == 0) {   // first sight of this shape (or a stale graph): staging buffers now, eager forward by the caller
+    g.n_x = (size_t)cfg.in_dim * F * H * W; g.n_hint = (size_t)4 * F * H * W; g.n_y = (size_t)77 * cfg.context_dim; g.n_out = (size_t)cfg.out_dim * F * H * W;
+    auto need = [&](float*& p, size_t n) { return p ? 0 : rt::dev_malloc((void**)&p, n * 4); };
+    int rc = need(g.xt, g.n_x) | need(g.hint, g.n_hint) | need(g.tsin, (size_t)cfg.dim);
+    for (int b = 0; b < nb; ++b) rc |= need(g.y[b], g.n_y) | need(g.out[b], g.n_out);
+    if (rc) { g.n_x = 0; return ctx->fail("unet_forward: out of device memory for the graph's staging buffers"); }
+    return 0;
+  }
+  if (!M.gstream && rt::stream_create(&M.gstream)) return ctx->fail("unet_forward: cannot create the graph stream");
+  hipStream_t user = ctx->stream, gs = M.gstream;
+  if (rt::stream_wait_stream(gs, user)) return ctx->fail("unet_forward: stream ordering failed");
+  std::vector<float> se;
+  host_sinusoidal(t, cfg.dim, se);
+  rt::memcpy_h2d(g.tsin, se.data(), (size_t)cfg.dim * 4, gs);
+  rt::stream_sync(gs);   // `se` is a stack temporary (the eager path has the same synchronisation point)
+  rt::memcpy_d2d(g.xt, xt, g.n_x * 4, gs);
+  rt::memcpy_d2d(g.hint, hint, g.n_hint * 4, gs);
+  for (int b = 0; b < nb; ++b) rt::memcpy_d2d(g.y[b], ys[b], g.n_y * 4, gs);
+  if (!g.captured) {
+    if (rt::capture_begin(gs)) return ctx->fail(std::string("unet_forward: hipStreamBeginCapture failed: ") + rt::last_error_string());
+    ctx->stream = gs;
+    const float* gys[2] = {g.y[0], g.y[1]};
+    float* gouts[2] = {g.out[0], g.out[1]};
+    const int rc = unet_forward_impl(ctx, g.xt, g.tsin, gys, g.hint, gouts, nb, F, H, W, nullptr, 0);
+    ctx->stream = user;
+    rt::GraphExec ex;
+    const int rc2 = rt::capture_end(gs, &ex);
+    if (rc) { if (!rc2) rt::graph_destroy(ex); return rc; }
+    if (rc2) return ctx->fail(std::string("unet_forward: graph capture / instantiation failed: ") + rt::last_error_string());
+    g.exec = ex; g.captured = true; g.pool_gen = ctx->pool.generation();
+  }
+  if (rt::graph_launch(g.exec, gs)) return ctx->fail(std::string("unet_forward: hipGraphLaunch failed: ") + rt::last_error_string());
+  for (int b = 0; b < nb; ++b) rt::memcpy_d2d(outs[b], g.out[b], g.n_out * 4, gs);
+  if (rt::stream_wait_stream(user, gs)) return ctx->fail("unet_forward: stream ordering failed");
+  *ran = true;
+  return 0;
 }
 
 int unet_forward_n(Ctx* ctx, const float* xt, long long t, const float* const* ys, const float* hint, float* const* outs, int nb,
                    int F, int H, int W, void* const* control_tap, int n_tap) {
   if (!ctx->unet) return ctx->fail("unet_forward: no model built (star_unet_build)");
   if (nb < 1 || nb > 2) return ctx->fail("unet_forward: 1 or 2 guidance branches");
-  const UNetModel& M = *ctx->unet;
+  UNetModel& M = *ctx->unet;
   const UNetCfg& cfg = M.cfg;
   if (F < 1 || F > 128) return ctx->fail("unet_forward: 1..128 frames per chunk");
   {  // legal latent sizes: every Downsample/Upsample pair must round-trip (H = 2 mod 8, W = 0 mod 8 for 3 levels)
@@ -407,6 +464,26 @@ int unet_forward_n(Ctx* ctx, const float* xt, long long t, const float* const* y
     for (int i = 0; i < cfg.n_levels - 1; ++i) { h = 2 * h - 2; w *= 2; }
     if (h != H || w != W) return ctx->fail("unet_forward: illegal latent size (need H = 2 mod 8, W = 0 mod 8)");
   }
+  if (ctx->unet_graph && rt::graphs_available && !ctx->profiling && !control_tap) {
+    bool ran = false;
+    if (unet_forward_graph(ctx, M, xt, t, ys, hint, outs, nb, F, H, W, &ran)) return 1;
+    if (ran) return 0;
+  }
+  Buf t_in(ctx, (size_t)cfg.dim * 4);
+  if (!t_in.p) return ctx->fail("out of device memory");
+  {
+    std::vector<float> se;
+    host_sinusoidal(t, cfg.dim, se);
+    rt::memcpy_h2d(t_in.p, se.data(), (size_t)cfg.dim * 4, ctx->stream);
+    rt::stream_sync(ctx->stream);  // `se` is a stack temporary
+  }
+  return unet_forward_impl(ctx, xt, t_in.as<float>(), ys, hint, outs, nb, F, H, W, control_tap, n_tap);
+}
+
+static int unet_forward_impl(Ctx* ctx, const float* xt, const float* tsin, const float* const* ys, const float* hint, float* const* outs, int nb,
+                             int F, int H, int W, void* const* control_tap, int n_tap) {
+  const UNetModel& M = *ctx->unet;
+  const UNetCfg& cfg = M.cfg;
   Fwd f; f.ctx = ctx; f.F = F; f.es = ctx->esize(); f.ctx_dim = cfg.context_dim; f.embed_dim = cfg.embed_dim();
   f.nb = nb;
   const int E = cfg.embed_dim();
@@ -418,9 +495,9 @@ int unet_forward_n(Ctx* ctx, const float* xt, long long t, const float* const* y
     f.contexts[b] = ctxT[b].p;
   }
   f.context = f.contexts[0];
-  Buf emb_main(ctx, (size_t)E * 4), emb_ctrl(ctx, (size_t)E * 4), t_in(ctx, (size_t)cfg.dim * 4), t_mid(ctx, (size_t)E * 4);
-  if (time_embedding(ctx, M.main, t, cfg.dim, E, t_in, t_mid, emb_main.as<float>())) return 1;
-  if (time_embedding(ctx, M.control, t, cfg.dim, E, t_in, t_mid, emb_ctrl.as<float>())) return 1;
+  Buf emb_main(ctx, (size_t)E * 4), emb_ctrl(ctx, (size_t)E * 4), t_mid(ctx, (size_t)E * 4);
+  if (time_embedding(ctx, M.main, tsin, cfg.dim, E, t_mid, emb_main.as<float>())) return 1;
+  if (time_embedding(ctx, M.control, tsin, cfg.dim, E, t_mid, emb_ctrl.as<float>())) return 1;
 
   // im2col rows of x (shared by both nets' stem convs) and of the hint
   Buf xcols(ctx, (size_t)tok * 64 * f.es), hcols(ctx, (size_t)tok * 64 * f.es);

@@ -1,5 +1,7 @@
 // unet.h -- host-side model of ControlledV2VUNet + VideoControlNet for the C++ graph executor.
 #pragma once
+#include <array>
+#include <map>
 #include "graph.h"
 #include <string>
 #include <vector>
@@ -55,10 +57,22 @@ struct Net {
   LinW out_conv;
 };
 
+// one captured forward (hipGraph) per (guidance branches, frames, latent size): the launch sequence of a forward depends on nothing
+// else.  Inputs and outputs go through staging buffers the graph was captured with; the sinusoidal timestep row is refreshed in
+// `tsin` before every launch.  Pool blocks the graph addresses stay cached between launches; `pool_gen` detects a trimmed pool.
+struct UNetGraph {
+  rt::GraphExec exec;
+  bool captured = false;
+  uint64_t pool_gen = 0;
+  float* xt = nullptr; float* hint = nullptr; float* y[2] = {nullptr, nullptr}; float* out[2] = {nullptr, nullptr}; float* tsin = nullptr;
+  size_t n_x = 0, n_hint = 0, n_y = 0, n_out = 0;
+};
 struct UNetModel {
   UNetCfg cfg;
   Net main, control;
   std::vector<void*> owned;   // device allocations
+  std::map<std::array<int, 4>, UNetGraph> graphs;   // key: {nb, F, H, W}
+  hipStream_t gstream = nullptr;                     // capture / replay stream
   ~UNetModel();
 };
 

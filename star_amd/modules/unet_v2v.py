@@ -7,6 +7,7 @@ tensors to the C ABI (star_load_tensor + star_unet_build), and `__call__` is one
 star_unet_forward on the caller's stream.
 """
 import ctypes
+import os
 
 import torch
 
@@ -33,6 +34,7 @@ def _bind(lib):
     lib.unet_forward_cfg = L._sig(c, "star_unet_forward_cfg", i32, vp, vp, i64, vp, vp, vp, vp, vp, i32, i32, i32)
     lib.module_run = L._sig(c, "star_module_run", i32, vp, i32, ctypes.c_char_p, i32, i32, i32, i32, i32, vp, vp, vp, vp, i32, i32, i32)
     lib.clear_staged = L._sig(c, "star_clear_staged", i32, vp)
+    lib.unet_graph = L._sig(c, "star_unet_graph", i32, vp, i32)
     lib._unet_bound = True
 
 
@@ -69,6 +71,7 @@ class ControlledV2VUNet:
         self.batch = 1
         self.training = False
         self._pending_sd = None
+        self._graph = os.environ.get("STAR_UNET_GRAPH", "0") not in ("", "0")
 
     # -- reference-style fluent no-ops
     def to(self, device):
@@ -139,6 +142,16 @@ class ControlledV2VUNet:
             scale /= 2.0
         c.attn_levels = levels
         self.ctx._check(self.ctx.lib.unet_build(self.ctx.h, ctypes.byref(c)), "unet_build")
+        if self._graph:
+            self.ctx._check(self.ctx.lib.unet_graph(self.ctx.h, 1), "unet_graph")
+
+    def use_graph(self, enable=True):
+        """star_unet_graph: replay the forward of each (branches, frames, latent size) from a captured hipGraph (bit-identical results;
+        default: the STAR_UNET_GRAPH environment variable, else off)."""
+        self._graph = bool(enable)
+        if self.ctx is not None:
+            self.ctx._check(self.ctx.lib.unet_graph(self.ctx.h, int(self._graph)), "unet_graph")
+        return self
 
     def release_host_weights(self):
         self._pending_sd = None

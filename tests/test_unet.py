@@ -174,6 +174,41 @@ def test_cfg_pair_is_bit_identical_to_two_forwards(backend, request):
     assert rel_rms(pa, pb) > 1e-2
 
 
+def test_graph_replay_is_bit_identical_to_eager(backend, request):
+    """star_unet_graph: the second forward of a shape is captured into a hipGraph, later ones replay it through staging buffers;
+    outputs must equal the eager path bit for bit across timesteps and inputs, for the single forward and the CFG pair.  (On the
+    emulator there is no graph runtime: the switch is accepted and the eager path keeps running.)"""
+    net = _small_model(backend, torch.float16, request)
+    dev = net.ctx.torch_device
+    f = 1 if backend == "emu" else 5
+    cases = [(11, 500), (12, 30), (11, 999)] if backend != "emu" else [(11, 500)]
+    eager = []
+    for seed, tv in cases:
+        x, _, y, hint = unet_inputs(SMALL_TEST_CONFIG, f, 10, 8, seed)
+        y2 = torch.randn(y.shape, generator=torch.Generator().manual_seed(seed + 100))
+        t = torch.tensor([tv])
+        eager.append((net(x.to(dev), t=t, y=y.to(dev), hint=hint.to(dev)).clone(),
+                      None if backend == "emu" else tuple(o.clone() for o in net.forward_cfg_pair(x.to(dev), t, y.to(dev), y2.to(dev), hint=hint.to(dev)))))
+    net.use_graph(True)
+    try:
+        for rep in range(2 if backend != "emu" else 1):     # pass 0: eager warm-up, capture, replay; pass 1: replays only
+            for (seed, tv), (e1, e2) in zip(cases, eager):
+                x, _, y, hint = unet_inputs(SMALL_TEST_CONFIG, f, 10, 8, seed)
+                y2 = torch.randn(y.shape, generator=torch.Generator().manual_seed(seed + 100))
+                t = torch.tensor([tv])
+                assert torch.equal(net(x.to(dev), t=t, y=y.to(dev), hint=hint.to(dev)), e1)
+                if e2 is not None:
+                    pa, pb = net.forward_cfg_pair(x.to(dev), t, y.to(dev), y2.to(dev), hint=hint.to(dev))
+                    assert torch.equal(pa, e2[0]) and torch.equal(pb, e2[1])
+        if backend != "emu":   # a trimmed pool invalidates the captured addresses: the forward must notice and re-capture
+            net.ctx.trim()
+            for _ in range(3):
+                x, _, y, hint = unet_inputs(SMALL_TEST_CONFIG, f, 10, 8, cases[0][0])
+                assert torch.equal(net(x.to(dev), t=torch.tensor([cases[0][1]]), y=y.to(dev), hint=hint.to(dev)), eager[0][0])
+    finally:
+        net.use_graph(False)
+
+
 def test_illegal_latent_size_is_rejected(backend, request):
     from star_amd.lib import StarError
     net = _small_model(backend, torch.float16, request)
