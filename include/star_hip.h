@@ -137,7 +137,7 @@ int star_unet_forward(star_ctx* ctx, const float* xt, int64_t t, const float* y,
  * self-attention of each net's first spatial transformer) is computed once. */
 int star_unet_forward_cfg(star_ctx* ctx, const float* xt, int64_t t, const float* y_cond, const float* y_uncond,
                           const float* hint, float* out_cond, float* out_uncond, int32_t f, int32_t h, int32_t w);
-/* Replay the UNet forward from a captured hipGraph (off by default).  A forward is a fixed sequence of ~4700 kernel launches that
+/* Replay the UNet forward from a captured hipGraph (off by default).  A forward is a fixed sequence of a few thousand kernel launches (about 3400 per CFG pair at cfg2 size) that
  * depends on (guidance branches, f, h, w) only; with enable != 0 the first forward of a shape runs as usual (it sizes the activation
  * pool), the second is captured on a stream the context owns, later ones copy xt / y / hint into the graph's staging buffers, refresh
  * the timestep row and issue one hipGraphLaunch, ordered against the context's stream with events.  Results are bit-identical to the

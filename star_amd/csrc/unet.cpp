@@ -402,7 +402,7 @@ static int time_embedding(Ctx* ctx, const Net& net, const float* tsin, int dim, 
 static int unet_forward_impl(Ctx* ctx, const float* xt, const float* tsin, const float* const* ys, const float* hint, float* const* outs, int nb,
                              int F, int H, int W, void* const* control_tap, int n_tap);
 
-// One forward = a fixed sequence of ~4700 kernel launches that depends on (branches, frames, latent size) only.  With
+// One forward = a fixed sequence of a few thousand kernel launches (about 3400 per CFG pair at cfg2 size) that depends on (branches, frames, latent size) only.  With
 // star_unet_graph(ctx, 1) the second forward of a shape is captured into a hipGraph and later ones replay it: the caller's tensors
 // are copied into the staging buffers the graph was captured with, the sinusoidal row is refreshed, one hipGraphLaunch replaces
 // the launches.  The first forward of a shape always runs eagerly: it sizes the activation pool and sets the kernels' LDS
