@@ -402,8 +402,8 @@ static int time_embedding(Ctx* ctx, const Net& net, const float* tsin, int dim, 
 static int unet_forward_impl(Ctx* ctx, const float* xt, const float* tsin, const float* const* ys, const float* hint, float* const* outs, int nb,
                              int F, int H, int W, void* const* control_tap, int n_tap);
 
-// One forward = a fixed sequence of a few thousand kernel launches (about 3400 per CFG pair at cfg2 size) that depends on (branches, frames, latent size) only.  With
-// star_unet_graph(ctx, 1) the second forward of a shape is captured into a hipGraph and later ones replay it: the caller's tensors
+// One forward = a fixed sequence of a few thousand kernel launches (about 3400 per CFG pair at cfg2 size) that depends on
+// (branches, frames, latent size) only.  With star_unet_graph(ctx, 1) the second forward of a shape is captured into a hipGraph and later ones replay it: the caller's tensors
 // are copied into the staging buffers the graph was captured with, the sinusoidal row is refreshed, one hipGraphLaunch replaces
 // the launches.  The first forward of a shape always runs eagerly: it sizes the activation pool and sets the kernels' LDS
 // attributes, neither of which may happen under capture.
@@ -433,6 +433,7 @@ static int unet_forward_graph(Ctx* ctx, UNetModel& M, const float* xt, long long
   for (int b = 0; b < nb; ++b) rt::memcpy_d2d(g.y[b], ys[b], g.n_y * 4, gs);
   if (!g.captured) {
     if (rt::capture_begin(gs)) return ctx->fail(std::string("unet_forward: hipStreamBeginCapture failed: ") + rt::last_error_string());
+    const uint64_t gen0 = ctx->pool.generation();
     ctx->stream = gs;
     const float* gys[2] = {g.y[0], g.y[1]};
     float* gouts[2] = {g.out[0], g.out[1]};
@@ -442,7 +443,12 @@ static int unet_forward_graph(Ctx* ctx, UNetModel& M, const float* xt, long long
     const int rc2 = rt::capture_end(gs, &ex);
     if (rc) { if (!rc2) rt::graph_destroy(ex); return rc; }
     if (rc2) return ctx->fail(std::string("unet_forward: graph capture / instantiation failed: ") + rt::last_error_string());
-    g.exec = ex; g.captured = true; g.pool_gen = ctx->pool.generation();
+    if (ctx->pool.generation() != gen0) {   // the pool dropped its cache while the forward was being recorded (an allocation did not fit):
+      rt::graph_destroy(ex);                // blocks recorded earlier in this capture may be gone -- nothing was launched, start over eagerly
+      g.n_x = 0;
+      return 0;
+    }
+    g.exec = ex; g.captured = true; g.pool_gen = gen0;
   }
   if (rt::graph_launch(g.exec, gs)) return ctx->fail(std::string("unet_forward: hipGraphLaunch failed: ") + rt::last_error_string());
   for (int b = 0; b < nb; ++b) rt::memcpy_d2d(outs[b], g.out[b], g.n_out * 4, gs);
