@@ -208,9 +208,7 @@ gemm_kernel(const GemmParams p) {
   const int nk = p.K / BK;
   int tap = 0, c0 = 0;  // (tap, channel offset) of the K tile being staged
 
-  // LDS of the 2-stage loop: [A stage 0 | A stage 1 | W stage 0 | W stage 1] -- with the stage a compile-time constant of the
-  // unrolled loop, every fragment read is (loop-invariant register) + (16-bit immediate)
-  // one K tile's copies as separately placeable pieces (the scheduled loop puts them between MFMAs): stage_pre() fixes the
+  // One K tile's copies as separately placeable pieces (the scheduled loop puts them between MFMAs): stage_pre() fixes the
   // tile's uniform terms, stage_piece<J>() issues copy J (0..NA-1: A, NA..NA+NW-1: W), stage_post() advances (tap, c0)
   int st_ky = 0, st_kx = 0, st_tap_off = 0;
   uint32_t st_tap_bit = 1;
@@ -248,7 +246,8 @@ gemm_kernel(const GemmParams p) {
       if (c0 >= p.Cin) { c0 = 0; ++tap; }
     }
   };
-  // LDS of the 2-stage loop: [A stage 0 | A stage 1 | W stage 0 | W stage 1]
+  // LDS of the 2-stage loop: [A stage 0 | A stage 1 | W stage 0 | W stage 1] -- with the stage a compile-time constant of the
+  // unrolled loop, every fragment read is (loop-invariant register) + (16-bit immediate)
   auto stage = [&](int kt, int buf) {
     stage_pre();
     static_for<NA + NW>([&](auto jc) STAR_ALWAYS_INLINE { stage_piece(kt, buf, jc); });
