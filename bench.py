@@ -43,6 +43,114 @@ CONFIGS = {
 }
 
 
+class PowerSampler:
+    """socket power / shader clock of ONE GPU from sysfs hwmon, sampled on a host thread while kernels run (never rocm-smi beside a
+    kernel on this pool: profiles/r03_attn7_ab.txt).  The hwmon directory is matched to the torch device through its PCI address."""
+
+    def __init__(self, device_index=0, period=0.1):
+        import glob
+        self.period, self.samples, self._stop, self._th = period, [], False, None
+        cards = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"), key=lambda p: int(p.split("/card")[1].split("/")[0]))
+        self.path = None
+        try:
+            pr = torch.cuda.get_device_properties(device_index)
+            want = "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+            for c in cards:
+                if os.path.basename(os.path.realpath(os.path.join(c, "..", ".."))).lower().startswith(want):
+                    self.path = c
+        except Exception:
+            pass
+        if self.path is None and cards:
+            self.path = cards[min(device_index, len(cards) - 1)]
+
+    def _read(self):
+        try:
+            try:
+                w = int(open(self.path + "/power1_average").read()) / 1e6
+            except Exception:
+                w = int(open(self.path + "/power1_input").read()) / 1e6
+            return time.perf_counter(), w, int(open(self.path + "/freq1_input").read()) / 1e6
+        except Exception:
+            return None
+
+    def _run(self):
+        while not self._stop:
+            r = self._read()
+            if r:
+                self.samples.append(r)
+            time.sleep(self.period)
+
+    def start(self):
+        import threading
+        self.samples, self._stop = [], False
+        if self.path:
+            self._th = threading.Thread(target=self._run, daemon=True)
+            self._th.start()
+        return self
+
+    def stop(self):
+        self._stop = True
+        if self._th:
+            self._th.join()
+        return self
+
+    def summary(self, skip=0.0):
+        """mean / p5 / p95 of the samples taken later than `skip` seconds after the first one"""
+        ss = [x for x in self.samples if x[0] - self.samples[0][0] >= skip] if self.samples else []
+        if not ss:
+            return None
+
+        def stats(v):
+            v = sorted(v)
+            pick = lambda q: v[min(len(v) - 1, int(q * (len(v) - 1) + 0.5))]
+            return {"mean": round(sum(v) / len(v), 1), "p5": round(pick(0.05), 1), "p95": round(pick(0.95), 1)}
+        return {"socket_W": stats([x[1] for x in ss]), "sclk_MHz": stats([x[2] for x in ss]), "samples": len(ss), "period_s": self.period}
+
+
+def attention_operand_sweep(ctx, dev, device_index, heads=5, frames=32, hw=(122, 216), seconds=2.5):
+    """The dominant kernel alone, in a loop, on three operand sets of the cfg2 level-0 shape -- (i) N(0,1) (what random-init weights
+    feed it in the clip), (ii) the peaked-logit statistics of a TRAINED layer (tests/test_fullsize.py: shared low-rank component,
+    logits over +-40, a few keys carrying each row), (iii) zeros -- with the socket power and shader clock sampled beside each.
+    Outside the timed region; answers what the kernel's power-bound operating point is on each kind of data."""
+    H, W = hw
+    N, C = H * W, heads * 64
+    g = torch.Generator(device=dev).manual_seed(7)
+    sets = {}
+    sets["normal"] = torch.randn(frames, N, 3 * C, generator=g, device=dev, dtype=torch.float32).to(ctx.dtype)
+    yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float32, device=dev), torch.arange(W, dtype=torch.float32, device=dev), indexing="ij")
+    pos = torch.stack([torch.sin(yy / 9.0), torch.cos(yy / 9.0), torch.sin(xx / 13.0), torch.cos(xx / 13.0)], dim=-1).reshape(N, 4)
+    pk = torch.empty(frames, N, 3 * C, device=dev, dtype=ctx.dtype)
+    for h in range(heads):
+        basis = torch.randn(4, 64, generator=g, device=dev)
+        for part in range(2):
+            x = (pos @ basis * 2.5)[None] + torch.randn(frames, N, 64, generator=g, device=dev) * 0.7
+            if part == 1:
+                x[:, N - 3000:] *= 1.6
+            pk[:, :, part * C + h * 64: part * C + (h + 1) * 64] = x.to(ctx.dtype)
+        pk[:, :, 2 * C + h * 64: 2 * C + (h + 1) * 64] = torch.randn(frames, N, 64, generator=g, device=dev).to(ctx.dtype)
+    sets["peaked_trained_like"] = pk
+    sets["zeros"] = torch.zeros(frames, N, 3 * C, device=dev, dtype=ctx.dtype)
+    out = torch.empty(frames, N, C, device=dev, dtype=ctx.dtype)
+    flops = 4.0 * frames * heads * float(N) * N * 64
+    res = {}
+    for name, qkv in sets.items():
+        fn = lambda: ctx.attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], heads, out=out)
+        fn(); ctx.sync(); torch.cuda.synchronize()
+        ps = PowerSampler(device_index, 0.05).start()
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds:      # 10 launches (~0.25 s) per host synchronisation: the wall clock is the kernel time
+            for _ in range(10):
+                fn()
+            ctx.sync(); torch.cuda.synchronize(); n += 10
+        ms = (time.perf_counter() - t0) * 1e3 / n
+        ps.stop()
+        pw = ps.summary(skip=0.5)
+        res[name] = {"ms": round(ms, 3), "TFLOP/s": round(flops / ms / 1e9, 1), "frac_of_peak": round(flops / ms / 1e9 / (PEAK_BF16_MFMA / 1e12), 4),
+                     "socket_W": pw["socket_W"]["mean"] if pw else None, "sclk_MHz": pw["sclk_MHz"]["mean"] if pw else None, "launches": n}
+    del sets, pk, out
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -58,6 +166,7 @@ def main():
     ap.add_argument("--solver-mode", default=None, choices=["normal", "fast"])
     ap.add_argument("--max-chunk-len", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-operand-sweep", action="store_true", help="skip the post-run power / clock sweep of the attention kernel (N = 1 only)")
     ap.add_argument("--small", action="store_true", help="reduced-width smoke configuration (NOT the metric)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl = RCCL over xGMI (default); gloo only for single-GPU plumbing tests")
     ap.add_argument("--share-gpu0", action="store_true", help="TEST ONLY: every rank uses cuda:0 (1-GPU box, gloo backend)")
@@ -75,13 +184,10 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: launch ourselves under torch.distributed.run, one rank per GPU on this node (the driver's
         # own `python -m torch.distributed.run ... bench.py --gpus N` form arrives with WORLD_SIZE set and skips this)
-        import socket
+        # (--standalone: torchrun's own c10d rendezvous picks a free port itself -- no bind-then-close race with another process)
         import subprocess
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            port = sk.getsockname()[1]
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
-               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+               f"--nproc-per-node={args.gpus}", os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -141,8 +247,8 @@ def main():
                          guide_scale=7.5, max_chunk_len=args.max_chunk_len, return_device=True)
         if world > 1 and not shard_one_video:
             from star_amd.parallel import gather_frames
-            out = gather_frames(out)
-        return out
+            step.gathered = gather_frames(out, source=video, ctx=model.generator.ctx)   # uint8 frames (colour-fixed on the device): 1/4 of the xGMI bytes
+        return out          # this rank's own fp32 clip (finiteness is checked on it)
 
     def barrier():
         if world > 1:
@@ -155,11 +261,14 @@ def main():
     uctx, vctx = model.generator.ctx, model.vae.ctx
     barrier()
     uctx.profile_begin(); vctx.profile_begin()
+    power = PowerSampler(local_rank, 0.1).start() if rank == 0 else None
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     barrier()
     elapsed = time.perf_counter() - t0
+    if power:
+        power.stop()
     prof_u, prof_v = uctx.profile_end(), vctx.profile_end()
     if world > 1:
         import torch.distributed as dist
@@ -168,6 +277,19 @@ def main():
         elapsed = float(tmax.item())
     final = out[0] if isinstance(out, list) else out
     finite = bool(torch.isfinite(final).all())
+    # the reference's test() ends with `.cpu()` of the fp32 output (video_to_video_model.py:139); the timed region hands the frames
+    # over on the device (return_device=True: the colour fix / uint8 conversion that follows runs there) -- measured here, reported
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    host_copy = final.float().cpu()
+    d2h_ms = (time.perf_counter() - t1) * 1e3
+    d2h_bytes = host_copy.numel() * 4
+    del host_copy
+    sweep = None
+    if rank == 0 and world == 1 and not args.small and not args.no_operand_sweep:
+        del out, final
+        uctx.trim(); vctx.trim()
+        sweep = attention_operand_sweep(uctx, dev, local_rank)
 
     if rank == 0:
         frames_total = args.frames * (1 if shard_one_video else world) * args.steps
@@ -186,15 +308,21 @@ def main():
                 "algorithmic_flops_per_launch": l0_flops, "avg_launch_ms": a["max_flops_ms"],
                 "all_self_attn_launches": {"launches": a["launches"], "ms": a["ms"], "TFLOP/s": a["flops"] / max(a["ms"], 1e-9) / 1e9}}
         roof["frac"] = roof["achieved"] / roof["peak"] if roof["achieved"] else None
-        # measured, not nominal: the same kernel with its softmax VALU removed (MFMA + LDS + barriers only) runs 1568 TF/s on N(0,1)
-        # operands and 2068 on zeros -- the chip is power-limited and full-entropy operands cost a quarter of the clock
-        # (profiles/r02_power_limit.txt).  `peak` stays the nominal dense MFMA figure the metric is defined against.
-        # round 3 measured why (profiles/r03_attn7_ab.txt): on N(0,1) operands this kernel holds the socket at its power cap -- 1331 W at
-        # a sustained 1.83 GHz shader clock (2.40 GHz and 1006 W on zeros); a one-wave-per-SIMD software pipeline of the same
-        # arithmetic runs fewer instructions per cycle at 2.08 GHz and lands at the same time per launch.
-        roof["power"] = {"socket_W_on_random_operands": 1331, "sclk_GHz_on_random_operands": 1.83, "sclk_GHz_on_zeros": 2.40,
-                         "source": "profiles/r03_attn7_ab.txt (sysfs hwmon sampled beside the kernel)"}
-        roof["mfma_skeleton_ceiling_on_random_operands"] = {"TFLOP/s": 1568.0, "source": "profiles/r02_power_limit.txt (variant 16, N(0,1) f16)",
+        # power: sampled LIVE in this run (sysfs hwmon beside the kernels) -- over the whole timed region, and, after it, beside the
+        # dominant kernel alone on three operand sets (N(0,1) / trained-like peaked logits / zeros).  DESIGN.md section 3.6: on
+        # full-entropy operands this kernel holds the socket at its power cap and the shader clock falls; `peak` stays the nominal
+        # dense MFMA figure the metric is defined against.
+        roof["power"] = {"measured_live": bool(power and power.samples), "timed_region": power.summary() if power else None,
+                         "source": "sysfs hwmon (power1_average, freq1_input) sampled every 0.1 s on a host thread during the timed region",
+                         "dominant_kernel_alone": sweep,
+                         "dominant_kernel_alone_note": "L0 spatial self-attention of cfg2 (32 x 5 heads, N = 26352) looped ~2.5 s per operand set "
+                                                       "AFTER the timed region, hwmon sampled every 0.05 s beside it" if sweep else None}
+        if sweep and sweep.get("peaked_trained_like"):
+            pk_ = sweep["peaked_trained_like"]
+            roof["second_operating_point"] = {"operands": "trained-like peaked logits (tests/test_fullsize.py statistics) -- NOT the headline: the clip's own "
+                                                          "operands are the N(0,1)-like activations of random-init weights",
+                                              "achieved": pk_["TFLOP/s"], "frac": pk_["frac_of_peak"], "socket_W": pk_["socket_W"], "sclk_MHz": pk_["sclk_MHz"]}
+        roof["mfma_skeleton_ceiling_on_random_operands"] = {"TFLOP/s": 1568.0, "source": "static: profiles/r02_power_limit.txt (variant 16, N(0,1) f16), a round-2 measurement, not re-measured in this run",
                                                             "frac_of_it": roof["achieved"] / 1568.0 if roof["achieved"] else None}
         breakdown = {k: {"ms": round(v["ms"], 1), "launches": v["launches"],
                          "TFLOP/s": round(v["flops"] / v["ms"] / 1e9, 1) if v["ms"] and v["flops"] else None,
@@ -218,6 +346,9 @@ def main():
             "setup_s": {"weights": round(t_weights, 1), "load": round(t_load, 1)},
             "algorithmic_pflop_per_step": (2 * evals * cfg["chunks"] * cfg["fwd_tflop"] + args.frames * VAE_TFLOP_PER_FRAME * cfg["vae_scale"]) / 1e3
                                           if not args.small and not custom else None,
+            "timed_region_excludes": f"the final .cpu() of the fp32 output ({d2h_bytes / 1e6:.0f} MB, video_to_video_model.py:139): the frames are handed over "
+                                     f"on the device; that copy measured once after the timed region: {d2h_ms:.0f} ms (pageable host memory)",
+            "output_d2h_ms": round(d2h_ms, 1),
             "output_finite": finite, "hbm_pool_gb": {"unet": round(uctx.lib.pool_peak_bytes(uctx.h) / 2 ** 30, 1), "vae": round(vctx.lib.pool_peak_bytes(vctx.h) / 2 ** 30, 1)},
         }
         print(json.dumps(line), flush=True)

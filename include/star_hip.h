@@ -29,9 +29,10 @@ enum { STAR_F16 = 0, STAR_BF16 = 1, STAR_F32 = 2 };
 enum { STAR_A_PLAIN = 0, STAR_A_CONV3X3 = 1, STAR_A_CONV3X3_UP = 2, STAR_A_TCONV3 = 3 };
 /* epilogue flags of star_gemm */
 enum { STAR_EPI_BIAS = 1, STAR_EPI_RES = 2, STAR_EPI_GEGLU = 4, STAR_EPI_OUT_F32 = 8,
-       STAR_EPI_GELU_TANH = 16   /* out = gelu_tanh(acc + bias): the DiT MLP activation (plain-A layers, no residual) */ };
-/* (bit 32, the folded-LayerNorm epilogue, is internal to star_unet_forward: it needs per-row and per-column operands the descriptor
- * does not carry, and star_gemm rejects it) */
+       STAR_EPI_GELU_TANH = 16,  /* out = gelu_tanh(acc + bias): the DiT MLP activation (plain-A layers, no residual) */
+       STAR_EPI_ROWAFF = 32      /* a LayerNorm folded into this projection: out = a_m * acc + b_m * colsum[n] + bias[n] with the
+                                    star_gemm_desc.rowab / .colsum operands (plain-A layers, 16-bit output, no residual; needs
+                                    STAR_EPI_BIAS).  star_layer_norm_rowab produces rowab. */ };
 
 /* ---- context ------------------------------------------------------------ */
 /* replaces: VideoToVideo_sr.__init__ device selection (video_to_video_model.py:21-34,42) */
@@ -106,6 +107,12 @@ int star_group_norm(star_ctx* ctx, const void* x, int32_t ldx, void* y, int32_t 
 int star_layer_norm(star_ctx* ctx, const void* x, int32_t ldx, void* y, int32_t ldy, const float* gamma,
                     const float* beta, int32_t rows, int32_t C, float eps, int32_t mode, const float* gate_w,
                     float* maps, int32_t H, int32_t W);
+/* the statistics half of a LayerNorm that is folded into the projection behind it (STAR_EPI_ROWAFF): no normalised tensor is
+ * written; rowab[row] = (a, b) fp32 pairs with LN(gate * x) = (a * x + b) * gamma + beta (gate = the LIEM gate of `mode`, 1 for
+ * mode 0), which star_gemm applies as out = a_m * (x W'^T) + b_m * colsum[n] + bias'[n] with W' = gamma o W,
+ * colsum[n] = sum_k W'[n][k], bias'[n] = sum_k beta[k] W[n][k] + bias[n] (prepared once per layer by the caller). */
+int star_layer_norm_rowab(star_ctx* ctx, const void* x, int32_t ldx, float* rowab, int32_t rows, int32_t C, float eps, int32_t mode,
+                          const float* gate_w, float* maps, int32_t H, int32_t W);
 /* replaces: torch.cat([x, skip + control], dim=1) (unet_v2v.py:1792) and residual adds */
 int star_concat_add(star_ctx* ctx, const void* a, const void* b, const void* c, void* out, int32_t rows, int32_t C1, int32_t C2);
 int star_add(star_ctx* ctx, const void* a, const void* b, void* out, int64_t n);

@@ -156,6 +156,14 @@ int star_layer_norm(star_ctx* h, const void* x, int32_t ldx, void* y, int32_t ld
   if (h) rt::set_device(h->c.device);   // follow the context's device, not the caller's current one
   return finish(h, op_layer_norm(&h->c, x, ldx, y, ldy, gamma, beta, rows, C, eps, mode, gate_w, maps, H, W));
 }
+int star_layer_norm_rowab(star_ctx* h, const void* x, int32_t ldx, float* rowab, int32_t rows, int32_t C, float eps, int32_t mode,
+                          const float* gate_w, float* maps, int32_t H, int32_t W) {
+  if (h) rt::set_device(h->c.device);
+  if (!h) return 1;
+  if (!rowab) return finish(h, h->c.fail("layer_norm_rowab: null output"));
+  if (mode == LN_STATS_ONLY) return finish(h, h->c.fail("layer_norm_rowab: mode 3 (maps only) has no row statistics; use star_layer_norm"));
+  return finish(h, op_layer_norm(&h->c, x, ldx, nullptr, 8, nullptr, nullptr, rows, C, eps, mode, gate_w, maps, H, W, rowab));
+}
 int star_concat_add(star_ctx* h, const void* a, const void* b, const void* c, void* out, int32_t rows, int32_t C1, int32_t C2) {
   if (h) rt::set_device(h->c.device);   // follow the context's device, not the caller's current one
   return finish(h, op_concat_add(&h->c, a, b, c, out, rows, C1, C2));

@@ -23,8 +23,8 @@ static int launch_flash(Ctx* ctx, const AttnArgs& a) {
   const long long nblk = 8LL * p.nqb * ((BH + 7) / 8);
   p.variant = a.variant;
 #ifndef STAR_HOSTEMU
-  if (std::getenv("STAR_DEBUG_OCC")) {   // resident workgroups per CU of the product kernel (debug aid)
-    static bool once = false;
+  {   // resident workgroups per CU of the product kernel (debug aid; the environment is read once)
+    static bool once = std::getenv("STAR_DEBUG_OCC") == nullptr;
     if (!once) {
       once = true;
       int nb = -1;

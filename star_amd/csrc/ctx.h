@@ -13,6 +13,12 @@ enum DType : int { DT_F16 = 0, DT_BF16 = 1, DT_F32 = 2 };
 
 // size-bucketed caching allocator: every kernel runs on ctx->stream, so a freed
 // block may be handed out again immediately (stream order protects it).
+// INVARIANT the hipGraph replay of the UNet forward relies on (unet.cpp: unet_forward_graph): a captured graph bakes in the
+// addresses of blocks that are back on the free list once the capture ends; nothing pins them.  That is safe only while every
+// Buf is scoped to one C-ABI call on the context's single host thread -- a replay then finds the pool exactly as the capture
+// left it.  A Buf that outlives a call (a cached VAE / control buffer, a second thread on the context) could be handed one of
+// those blocks and would be overwritten by a replay: the replay path therefore checks in_use() == 0 and runs the eager
+// forward instead when anything is live; trim() bumps the generation, which invalidates the graphs.
 class Pool {
  public:
   ~Pool() { release(); }
@@ -63,6 +69,7 @@ class Pool {
   }
   size_t total() const { return total_; }
   size_t peak() const { return peak_; }
+  size_t in_use() const { return in_use_; }
   uint64_t generation() const { return gen_; }
  private:
   uint64_t gen_ = 0;

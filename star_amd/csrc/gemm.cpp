@@ -10,6 +10,23 @@ int launch_gemm_bf16(Ctx* ctx, const GemmArgs& a);
 bool gemm_astat_applies(const GemmArgs& a);          // gemm_as.cpp: A-stationary kernel for the wide short-K layers of level 0
 int launch_gemm_astat(Ctx* ctx, const GemmArgs& a);
 
+// A/B switches, read ONCE per process (the launch path runs ~3400 times per CFG forward: no environ scans there, and a concurrent
+// setenv from another Python thread cannot race a launch)
+struct GemmEnv {
+  bool no_astat; int group_m; bool has_group_m;
+  GemmEnv() {
+    no_astat = std::getenv("STAR_NO_ASTAT") != nullptr;
+    const char* e = std::getenv("STAR_GEMM_GROUP_M");
+    has_group_m = e != nullptr;
+    group_m = e ? std::atoi(e) : -1;
+  }
+};
+#ifdef STAR_BENCH_VARIANTS   // the A/B tools (tools/ab_gemm_*.py) flip the switches between launches of one process
+static GemmEnv gemm_env() { return GemmEnv(); }
+#else
+static const GemmEnv& gemm_env() { static const GemmEnv e; return e; }
+#endif
+
 int op_gemm(Ctx* ctx, const GemmArgs& a) {
   if (a.K % 64 != 0) return ctx->fail("gemm: K must be a multiple of 64");
   if (a.lda % 8 != 0) return ctx->fail("gemm: lda must be a multiple of 8");
@@ -33,14 +50,12 @@ int op_gemm(Ctx* ctx, const GemmArgs& a) {
   ProfScope ps(ctx, a.mode == A_PLAIN ? PK_GEMM : (a.mode == A_TCONV3 ? PK_TCONV : PK_CONV), 2.0 * a.M * (double)a.N * a.K,
                ((double)a.M * (a.mode == A_PLAIN ? a.K : a.Cin) + (double)a.M * ((a.epi & EPI_GEGLU) ? a.N / 2 : a.N)) * 2.0,
                a.M, a.N, a.K, a.epi);
-  if ((a.force_tile >= 30 && a.force_tile <= 35) || (a.force_tile == 0 && gemm_astat_applies(a) && !std::getenv("STAR_NO_ASTAT"))) return launch_gemm_astat(ctx, a);
-  if (a.group_m < 0) {   // A/B aid: STAR_GEMM_GROUP_M overrides the automatic choice of the tile walk (gemm.h)
-    if (const char* e = std::getenv("STAR_GEMM_GROUP_M")) {
-      GemmArgs b = a;
-      b.group_m = std::atoi(e);
-      if (ctx->dtype == DT_F16) return launch_gemm_f16(ctx, b);
-      if (ctx->dtype == DT_BF16) return launch_gemm_bf16(ctx, b);
-    }
+  if ((a.force_tile >= 30 && a.force_tile <= 35) || (a.force_tile == 0 && gemm_astat_applies(a) && !gemm_env().no_astat)) return launch_gemm_astat(ctx, a);
+  if (a.group_m < 0 && gemm_env().has_group_m) {   // A/B aid: STAR_GEMM_GROUP_M overrides the automatic choice of the tile walk (gemm.h)
+    GemmArgs b = a;
+    b.group_m = gemm_env().group_m;
+    if (ctx->dtype == DT_F16) return launch_gemm_f16(ctx, b);
+    if (ctx->dtype == DT_BF16) return launch_gemm_bf16(ctx, b);
   }
   if (ctx->dtype == DT_F16) return launch_gemm_f16(ctx, a);
   if (ctx->dtype == DT_BF16) return launch_gemm_bf16(ctx, a);

@@ -72,6 +72,12 @@ static int launch_gemm_t(Ctx* ctx, const GemmArgs& a) {
   return launch_gemm_f<T, BM, BN, WM, WN, MINW, false, STAGGER, PIPE, ALLEPI>(ctx, a);
 }
 
+#ifdef STAR_BENCH_VARIANTS
+static bool no_sched_env() { return std::getenv("STAR_NO_SCHED") != nullptr; }
+#else
+static bool no_sched_env() { static const bool v = std::getenv("STAR_NO_SCHED") != nullptr; return v; }   // read once (A/B switch)
+#endif
+
 template <class T>
 static int launch_gemm(Ctx* ctx, const GemmArgs& a) {
   int tile = a.force_tile;
@@ -88,7 +94,7 @@ static int launch_gemm(Ctx* ctx, const GemmArgs& a) {
     // with fewer tiles the 256 x 320 tile's smaller tail wins, and plain-A layers of these shapes tie
     const bool sched_ok = (a.mode == A_CONV3X3 || a.mode == A_TCONV3) && a.N % 256 == 0 && a.K >= 2560 &&
                           !(a.epi & (EPI_OUT_F32 | EPI_ROWAFF | EPI_GELU_TANH | EPI_GEGLU)) &&
-                          (int64_t)((a.M + 255) / 256) * (a.N / 256) >= 512 && !std::getenv("STAR_NO_SCHED");
+                          (int64_t)((a.M + 255) / 256) * (a.N / 256) >= 512 && !no_sched_env();
     if (sched_ok) tile = 17;
     else if (a.M <= 4096 && a.N <= 1024) tile = 3;                     // small problems: more, smaller tiles
     else if (!geglu && a.N % 320 == 0) tile = 2;                        // 320 / 640 / 960 / 1280 / 1920-wide layers

@@ -605,16 +605,18 @@ void rt_note_launch_error(const char* what);
   ::star_emu::launch((grid), (block), (smem), [&]() { kern(__VA_ARGS__); })
 #else
 // The dynamic-LDS opt-in (> 64 KB) is a per-DEVICE property of the function object: it is cached per kernel instantiation, call
-// site and device (a process may hold contexts on several GPUs; the cache is a racy-but-idempotent hint: at worst the attribute
+// site and device (a process may hold contexts on several GPUs: one table entry per device id below 64, no sharing; the cache is a racy-but-idempotent hint: at worst the attribute
 // is set twice).  A refused attribute or launch is remembered in star::rt::launch_error (checked at the end of every C-ABI call:
 // include/star_hip.h), never dropped.
 #define STAR_LAUNCH(kern, grid, block, smem, stream, ...)                                              \
   do {                                                                                                  \
     if ((smem) > 65536) {                                                                               \
-      static size_t star_attr_set_[16] = {0};                                                           \
+      static size_t star_attr_set_[64] = {0};                                                           \
+      size_t star_uncached_ = 0;                                                                        \
       int star_dev_ = 0;                                                                                \
       (void)hipGetDevice(&star_dev_);                                                                   \
-      size_t& star_cur_ = star_attr_set_[star_dev_ & 15];                                               \
+      /* one entry per visible device; a device id past the table is simply not cached (attribute set per launch) */ \
+      size_t& star_cur_ = (star_dev_ >= 0 && star_dev_ < 64) ? star_attr_set_[star_dev_] : star_uncached_; \
       if ((size_t)(smem) > star_cur_) {                                                                 \
         if (hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(smem)) != hipSuccess) \
           ::star::rt_note_launch_error(#kern ": dynamic LDS size refused");                             \

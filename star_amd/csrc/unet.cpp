@@ -421,6 +421,7 @@ static int unet_forward_graph(Ctx* ctx, UNetModel& M, const float* xt, long long
     if (rc) { g.n_x = 0; return ctx->fail("unet_forward: out of device memory for the graph's staging buffers"); }
     return 0;
   }
+  if (ctx->pool.in_use() != 0) return 0;   // a pool block is live across this call (ctx.h: Pool invariant): a replay could overwrite it -- eager forward
   if (!M.gstream && rt::stream_create(&M.gstream)) return ctx->fail("unet_forward: cannot create the graph stream");
   hipStream_t user = ctx->stream, gs = M.gstream;
   if (rt::stream_wait_stream(gs, user)) return ctx->fail("unet_forward: stream ordering failed");

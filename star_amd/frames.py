@@ -16,10 +16,9 @@ def register_context(ctx):
 
 
 def context_for(device=None):
-    """The registered context of `device` (index, torch.device or None = device 0); created on first use."""
-    if isinstance(device, torch.device):
-        device = device.index or 0
-    device = int(device or 0)
+    """The registered context of `device` (index, torch.device, or None / an index-less 'cuda' = this process's current device);
+    created on first use."""
+    device = L.device_index(torch.device("cuda") if device is None else device)
     if device not in _contexts:
         _contexts[device] = L.Context(device, torch.float16)
     return _contexts[device]

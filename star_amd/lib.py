@@ -109,6 +109,7 @@ class Library:
         self.temporal_attn_fwd = _sig(c, "star_temporal_attn_fwd", i32, vp, ctypes.POINTER(TAttnDesc))
         self.group_norm = _sig(c, "star_group_norm", i32, vp, vp, i32, vp, i32, vp, vp, i32, i32, i32, f32, i32)
         self.layer_norm = _sig(c, "star_layer_norm", i32, vp, vp, i32, vp, i32, vp, vp, i32, i32, f32, i32, vp, vp, i32, i32)
+        self.layer_norm_rowab = _sig(c, "star_layer_norm_rowab", i32, vp, vp, i32, vp, i32, i32, f32, i32, vp, vp, i32, i32)
         self.concat_add = _sig(c, "star_concat_add", i32, vp, vp, vp, vp, vp, i32, i32, i32)
         self.add = _sig(c, "star_add", i32, vp, vp, vp, vp, i64)
         self.stem_im2col = _sig(c, "star_stem_im2col", i32, vp, vp, vp, i32, i32, i32, i32)
@@ -140,13 +141,22 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
+def device_index(device):
+    """int | torch.device -> device ordinal; a 'cuda' device without an index means this process's CURRENT device (one rank per GPU:
+    never silently GPU 0)"""
+    if isinstance(device, torch.device):
+        if device.index is not None:
+            return device.index
+        return torch.cuda.current_device() if device.type == "cuda" and torch.cuda.is_available() else 0
+    return int(device)
+
+
 class Context:
     """One star_ctx: a device, a compute dtype (fp16/bf16), a stream, a workspace pool."""
 
     def __init__(self, device=0, dtype=torch.float16, library=None):
         self.lib = library or default_library()
-        if isinstance(device, torch.device):
-            device = device.index or 0
+        device = device_index(device)
         if not self.lib.is_hostemu and not torch.cuda.is_available():
             raise StarError("star_amd needs a ROCm GPU (gfx950); no CPU fallback exists for the HIP hot path")
         self.device_index = int(device)
@@ -314,6 +324,15 @@ class Context:
         self._check(self.lib.layer_norm(self.h, _ptr(x), x.stride(0), _ptr(out), out.stride(0), _ptr(gamma), _ptr(beta),
                                         rows, C, float(eps), mode, _ptr(gate_w), _ptr(maps), H, W), "layer_norm")
         return out
+
+    def layer_norm_rowab(self, x, eps=1e-5, mode=LN_PLAIN, gate_w=None, maps=None, H=0, W=0):
+        """row statistics of a LayerNorm folded into the projection behind it: rowab[row] = (a, b), LN(gate x) = (a x + b) gamma + beta"""
+        self._chk_tensor(x, self.dtype)
+        rows, C = x.shape
+        rowab = torch.empty(rows, 2, dtype=torch.float32, device=self.torch_device)
+        self._check(self.lib.layer_norm_rowab(self.h, _ptr(x), x.stride(0), _ptr(rowab), rows, C, float(eps), mode, _ptr(gate_w),
+                                              _ptr(maps), H, W), "layer_norm_rowab")
+        return rowab
 
     def concat_add(self, a, b, c=None):
         rows, C1 = a.shape

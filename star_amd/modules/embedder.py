@@ -133,7 +133,7 @@ class FrozenOpenCLIPEmbedder(nn.Module):
             from .. import lib as L
             from .unet_v2v import stage_tensor
             dev = torch.device(self.device)
-            ctx = L.Context(dev.index or 0, self._hip_dtype, self._library)
+            ctx = L.Context(L.device_index(dev), self._hip_dtype, self._library)   # 'cuda' without an index = this rank's CURRENT device, not GPU 0
             sd = self.model.state_dict()
             blocks = self.model.transformer.resblocks
             keys = ["ln_final.weight", "ln_final.bias"]
@@ -146,7 +146,11 @@ class FrozenOpenCLIPEmbedder(nn.Module):
             width = self.model.ln_final.weight.shape[0]
             heads = blocks[0].attn.num_heads
             ctx._check(ctx.lib.text_build(ctx.h, int(width), int(heads), len(blocks)), "text_build")
-            self._hip = (ctx, L, width, len(blocks))
+            n_blocks = len(blocks)
+            # the runtime holds its own 16-bit copy: the fp32 torch blocks leave the device (0.6 GB at full size); the embedding
+            # tables stay where the tokens are looked up
+            self.model.transformer.resblocks.to("cpu")
+            self._hip = (ctx, L, width, n_blocks)
         return self._hip
 
     def encode_with_transformer(self, text):
@@ -159,7 +163,7 @@ class FrozenOpenCLIPEmbedder(nn.Module):
             xin = x.to(device=ctx.torch_device, dtype=self._hip_dtype).reshape(B * T, width).contiguous()
             out = torch.empty_like(xin)
             ctx._check(ctx.lib.text_forward(ctx.h, L._ptr(xin), B, T, n_blocks - self.layer_idx, L._ptr(out)), "text_forward")
-            return out.reshape(B, T, width).float()
+            return out.reshape(B, T, width).float().to(x.device)   # back on the caller's device (the tower's context may sit elsewhere)
         x = x.permute(1, 0, 2)                           # NLD -> LND
         x = self.text_transformer_forward(x, attn_mask=self.model.attn_mask)
         x = x.permute(1, 0, 2)

@@ -76,8 +76,7 @@ class ControlledV2VUNet:
     # -- reference-style fluent no-ops
     def to(self, device):
         if isinstance(device, (torch.device, str)):
-            d = torch.device(device)
-            self._device = d.index or 0
+            self._device = L.device_index(torch.device(device))
         return self
 
     def eval(self):

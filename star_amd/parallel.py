@@ -31,6 +31,14 @@ def _gather_ints(vec, group, device):
     return torch.stack(outs).cpu()
 
 
+def _all_gather_one(t, world, group):
+    """all_gather_into_tensor of equally shaped contiguous tensors (the concatenated-along-dim-0 output form, which both RCCL and
+    gloo accept) -> list of per-rank views of one allocation"""
+    flat = torch.empty([world * t.shape[0]] + list(t.shape[1:]), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(flat, t, group=group)
+    return list(flat.chunk(world, 0))
+
+
 class _RaggedPlan:
     """Who sends how many parts of which size: static for a given (latent shape, chunk list) / (frame count, groups), so it
     is exchanged ONCE (two small all-gathers, no reduce, no pickling, any number of parts) and cached under a key every rank
@@ -75,18 +83,25 @@ def _all_gather_ragged(parts, dim, group, cache=None, key=None):
         if cache is not None and key is not None:
             cache[key] = plan
     assert plan.own == [q.shape[dim] for q in parts], "ragged-gather plan does not match this call (key collision)"
-    buf = torch.zeros(plan.pad_shape, dtype=plan.dtype, device=device)
-    if parts:
-        cat = torch.cat(parts, dim=dim)
-        buf.narrow(dim, 0, cat.shape[dim]).copy_(cat)
+    # every rank sends ONE buffer padded along `dim` to the largest per-rank total.  When all ranks hold the same total (the cfg3
+    # layout: 8 chunks on 8 ranks, 24 decode groups on 8 ranks) nothing is padded, and the pad region is never read otherwise, so
+    # the buffer is not zero-filled either way.
+    total = sum(plan.own)
+    if parts and len(parts) == 1 and total == plan.pad_shape[dim] and parts[0].is_contiguous():
+        buf = parts[0]                                   # one part of full size: send it as it is
+    else:
+        buf = torch.empty(plan.pad_shape, dtype=plan.dtype, device=device)
+        off = 0
+        for q in parts:
+            buf.narrow(dim, off, q.shape[dim]).copy_(q)
+            off += q.shape[dim]
     if dist.get_backend(group) == "gloo" and buf.is_cuda:   # plumbing tests on a 1-GPU box: stage through the host
         host = buf.cpu()
         houts = [torch.empty_like(host) for _ in range(world)]
         dist.all_gather(houts, host, group=group)
         outs = [o.to(device) for o in houts]
     else:
-        outs = [torch.empty_like(buf) for _ in range(world)]
-        dist.all_gather(outs, buf, group=group)      # RCCL all-gather over xGMI (C1 / C2)
+        outs = _all_gather_one(buf.contiguous(), world, group)      # ONE RCCL all-gather over xGMI (C1 / C2) into one allocation
     result = []
     for r in range(world):
         off, lst = 0, []
@@ -134,14 +149,23 @@ class FrameSharder:
         return torch.cat(out)
 
 
-def gather_frames(frames, group=None):
-    """C1: all-gather of each rank's decoded clip [1, 3, F, H, W] -> list of world tensors (same shape on all ranks)."""
+def gather_frames(frames, group=None, source=None, ctx=None):
+    """C1: all-gather of each rank's decoded clip -> list of world tensors (same shape on all ranks).
+
+    frames: the pipeline output [1, 3, F, H, W] fp32 (any dtype / shape is gathered as it is).  With `source` (the rank's
+    low-resolution clip [F, 3, h, w] in [-1, 1]) the frames first go through tensor2vid + adain_color_fix + `.astype('uint8')`
+    ON THE DEVICE (star_color_fix_u8; inference_sr.py:47-48 + inference_utils.py:92 -- what is done to them before they are saved
+    anyway) and the uint8 [F, H, W, 3] frames are gathered: a quarter of the bytes over xGMI (157 MB instead of 628 MB per rank at
+    cfg2, 1.26 GB instead of 5 GB landed per rank at N = 8)."""
     world, _ = _world(group)
+    if source is not None:
+        from . import frames as _frames
+        c = ctx if ctx is not None else _frames.context_for(frames.device)
+        frames = c.color_fix(frames.float(), source.float(), as_uint8=True)
+    frames = frames.contiguous()
     if dist.get_backend(group) == "gloo" and frames.is_cuda:   # plumbing tests on a 1-GPU box: stage through the host
-        host = frames.contiguous().cpu()
+        host = frames.cpu()
         outs = [torch.empty_like(host) for _ in range(world)]
         dist.all_gather(outs, host, group=group)
         return [o.to(frames.device) for o in outs]
-    outs = [torch.empty_like(frames) for _ in range(world)]
-    dist.all_gather(outs, frames.contiguous(), group=group)
-    return outs
+    return _all_gather_one(frames, world, group)

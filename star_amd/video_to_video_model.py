@@ -19,6 +19,7 @@ import torch
 import torch.nn.functional as F
 
 from . import frames
+from . import lib as L
 from .diffusion import GaussianDiffusion, noise_schedule
 from .geometry import make_chunks, pad_to_fit, sliding_windows_1d  # noqa: F401  (re-exported like the reference module)
 from .modules.unet_v2v import ControlledV2VUNet
@@ -56,7 +57,8 @@ class VideoToVideo_sr:
         self.opt = opt
         self.device = torch.device(device)
         dtype = _opt(opt, "dtype", torch.float16)
-        dev_index = self.device.index or 0
+        # 'cuda' without an index = this rank's current device (never silently GPU 0)
+        dev_index = L.device_index(self.device)
         library = _opt(opt, "library")             # tests may pass the emulator build explicitly
 
         # text encoder (video_to_video_model.py:26-29).  opt.text_encoder: any callable str -> [1, 77, 1024]; otherwise the
@@ -68,7 +70,8 @@ class VideoToVideo_sr:
             try:
                 from .modules.embedder import FrozenOpenCLIPEmbedder
                 self.text_encoder = FrozenOpenCLIPEmbedder(device=self.device, pretrained="laion2b_s32b_b79k",
-                                                           text_state_dict=_opt(opt, "text_state_dict"), tokenizer=_opt(opt, "tokenizer"))
+                                                           text_state_dict=_opt(opt, "text_state_dict"), tokenizer=_opt(opt, "tokenizer"),
+                                                           dtype=dtype, library=library, runtime=_opt(opt, "text_runtime"))
             except ImportError as e:     # open_clip missing and no weights / tokenizer given: only prompt STRINGS are affected
                 self._text_encoder_error = str(e)
 

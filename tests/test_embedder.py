@@ -1,6 +1,7 @@
 """Text-encoder wrapper (star_amd/modules/embedder.py; reference video_to_video/modules/embedder.py:12-72): the prompt-string path
 with a stub tokenizer, the penultimate-layer rule, the causal mask, and the restated OpenCLIP text block against an independent
-statement on F.multi_head_attention_forward.  open_clip is not installed in this image: PARITY UNPINNED against open_clip itself."""
+statement on F.multi_head_attention_forward.  open_clip is not installed in this image; the tower is CROSS-PINNED to the HuggingFace
+CLIPTextModel implementation of the same architecture (test_text_tower_is_cross_pinned_to_the_hf_clip_implementation)."""
 import os
 import sys
 
@@ -8,7 +9,8 @@ import pytest
 import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
-from text_oracle import reference_block  # noqa: E402
+from text_oracle import (hf_clip_text_model, hf_penultimate_embedding, hf_to_open_clip_state_dict, oracle_tower,  # noqa: E402
+                         reference_block)
 from star_amd.modules.embedder import FrozenOpenCLIPEmbedder, OpenCLIPTextTransformer  # noqa: E402
 from util import BACKENDS  # noqa: E402
 
@@ -101,6 +103,51 @@ def test_text_tower_on_the_hip_runtime_matches_the_torch_tower(backend, dtype, r
     a = hip(["hello world"])
     b = hip(["hello there"])
     assert float((a[0, :6] - b[0, :6]).abs().max()) == 0.0 and float((a[0, 8:] - b[0, 8:]).abs().max()) > 0      # causal on the HIP path too
+
+
+@pytest.mark.parametrize("size", ["small", "vit_h_14"])
+def test_text_tower_is_cross_pinned_to_the_hf_clip_implementation(size):
+    """CROSS-PIN (HF), open_clip absent: transformers.CLIPTextModel -- an independent published implementation of the same pre-LN
+    causal text transformer, installed in this image -- random-init in ViT-H/14's text configuration, its state dict mapped to
+    open_clip's names; (a) the oracle's block statement (oracle/text_oracle.py) and (b) the product's nn.Module restatement
+    (star_amd/modules/embedder.py, what FrozenOpenCLIPEmbedder runs with runtime='torch') reproduce HF's penultimate hidden state +
+    final LayerNorm to fp32 round-off.  Reference call site: video_to_video/modules/embedder.py:49-72."""
+    width, heads, layers, vocab = (64, 4, 3, 100) if size == "small" else (1024, 16, 24, 49408)
+    hf = hf_clip_text_model(width, heads, layers, vocab_size=vocab, seed=3)
+    sd = hf_to_open_clip_state_dict(hf)
+    g = torch.Generator().manual_seed(5)
+    tokens = torch.randint(2, vocab - 1, (2, 77), generator=g)
+    tokens[0, 20:] = 1                                        # a short prompt: padding behind the end token
+    want = hf_penultimate_embedding(hf, tokens)
+    got_oracle = oracle_tower(sd, tokens, heads)
+    m = OpenCLIPTextTransformer(vocab_size=vocab, context_length=77, width=width, heads=heads, layers=layers).load_text_state_dict(sd)
+    got_module = FrozenOpenCLIPEmbedder(device="cpu", model=m, tokenizer=lambda t: tokens, runtime="torch")("x")
+    scale = float(want.abs().max())
+    eo, em = float((got_oracle - want).abs().max()), float((got_module - want).abs().max())
+    print(f"text tower {size}: |oracle - HF| = {eo:.2e}, |module - HF| = {em:.2e} (max |HF| = {scale:.2f})")
+    assert want.shape == (2, 77, width) and eo <= 1e-5 * max(1.0, scale) and em <= 1e-5 * max(1.0, scale)
+    # the 'last' layer too (one more block): HF's last_hidden_state is final_layer_norm(hidden_states[-1])
+    last = FrozenOpenCLIPEmbedder(device="cpu", model=m, tokenizer=lambda t: tokens, runtime="torch", layer="last")("x")
+    assert float((last - hf(input_ids=tokens).last_hidden_state).abs().max()) <= 1e-5 * max(1.0, scale)
+
+
+@pytest.mark.gpu
+def test_full_size_text_tower_on_the_gpu_against_hf_clip():
+    """the pinned chain on hardware: HF CLIPTextModel (fp32, CPU) in ViT-H/14's text configuration is the reference, its weights go
+    through the open_clip-named state dict into the HIP runtime (star_text_forward, fp16)."""
+    hf = hf_clip_text_model(seed=4)
+    sd = hf_to_open_clip_state_dict(hf)
+    g = torch.Generator().manual_seed(6)
+    tokens = torch.randint(2, 49000, (2, 77), generator=g)
+    tokens[0, 20:] = 1
+    want = hf_penultimate_embedding(hf, tokens)
+    m = OpenCLIPTextTransformer().load_text_state_dict(sd)
+    hip = FrozenOpenCLIPEmbedder(device="cuda:0", model=m, tokenizer=lambda t: tokens)
+    assert hip._use_hip()
+    z = hip("x")
+    print(f"text tower, 23 blocks + ln_final, fp16 HIP vs HF CLIPTextModel fp32: relative rms {_rel(z, want):.2e}")
+    assert z.shape == (2, 77, 1024) and torch.isfinite(z).all() and _rel(z, want) < 1e-2
+    assert next(m.transformer.resblocks.parameters()).device.type == "cpu"      # the torch blocks left the device once staged
 
 
 @pytest.mark.gpu

@@ -260,6 +260,51 @@ def test_gemm_folded_layer_norm_rows(ctx, dtype, M, N, geglu, tile):
     assert_close(out, ref, dtype, scale=6.0, what=f"gemm rowaff tile {tile}")
 
 
+def _header_enum(name):
+    """value of an enumerator of include/star_hip.h, parsed from the header text (a C caller sees only these names)"""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    txt = open(os.path.join(root, "include", "star_hip.h")).read()
+    m = re.search(r"\b%s\s*=\s*(\d+)" % name, txt)
+    assert m, f"{name} is not defined in include/star_hip.h"
+    return int(m.group(1))
+
+
+@pytest.mark.parametrize("M,N", [(300, 128), (520, 960)])
+def test_folded_layer_norm_through_the_header_names(ctx, dtype, M, N):
+    """A C caller's view of the folded LayerNorm: star_layer_norm_rowab for the row statistics, then star_gemm with
+    STAR_EPI_ROWAFF | STAR_EPI_BIAS and the rowab / colsum fields of star_gemm_desc -- using only names and values the header
+    defines -- equals LayerNorm (unet_v2v.py:448-450) followed by the Linear behind it (:151-155)."""
+    import ctypes
+    assert _header_enum("STAR_EPI_ROWAFF") == L.EPI_ROWAFF == 32 and _header_enum("STAR_EPI_BIAS") == 1
+    g = torch.Generator().manual_seed(M * 7 + N)
+    K = 320
+    x = (torch.randn(M, K, generator=g) * 1.5 + 0.3).to(dtype)
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dtype)
+    gamma, beta, b = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.1, torch.randn(N, generator=g)
+    ref = F.layer_norm(x.float(), (K,), gamma, beta, 1e-5) @ W.float().t() + b
+    Wf = (W.float() * gamma[None]).to(dtype)                  # W' = gamma o W (rounded as it will be multiplied)
+    colsum = Wf.float().sum(1).contiguous()
+    bias2 = (W.float() @ beta + b).contiguous()
+    xd, Wd, cs, b2 = dev(ctx, x), dev(ctx, Wf), dev(ctx, colsum), dev(ctx, bias2)
+    rowab = torch.empty(M, 2, dtype=torch.float32, device=ctx.torch_device)
+    rc = ctx.lib.layer_norm_rowab(ctx.h, ctypes.c_void_p(xd.data_ptr()), K, ctypes.c_void_p(rowab.data_ptr()), M, K, 1e-5, 0, None, None, 0, 0)
+    assert rc == 0, ctx.lib.last_error(ctx.h)
+    out = torch.empty(M, N, dtype=dtype, device=ctx.torch_device)
+    d = L.GemmDesc()
+    d.A, d.W, d.C, d.bias, d.res = xd.data_ptr(), Wd.data_ptr(), out.data_ptr(), b2.data_ptr(), None
+    d.M, d.N, d.K, d.lda, d.ldc, d.ldr = M, N, K, K, N, 0
+    d.mode, d.stride, d.pad_t, d.pad_l, d.up_crop = 0, 1, 1, 1, 1
+    d.epi = _header_enum("STAR_EPI_ROWAFF") | _header_enum("STAR_EPI_BIAS")
+    d.rowab, d.colsum = rowab.data_ptr(), cs.data_ptr()
+    rc = ctx.lib.gemm(ctx.h, ctypes.byref(d))
+    assert rc == 0, ctx.lib.last_error(ctx.h)
+    ctx.sync()
+    assert_close(out, ref, dtype, scale=6.0, what="folded LayerNorm through the header names")
+    # the statistics entry refuses what it cannot produce
+    assert ctx.lib.layer_norm_rowab(ctx.h, ctypes.c_void_p(xd.data_ptr()), K, None, M, K, 1e-5, 0, None, None, 0, 0) != 0
+
+
 def ref_attention(q, k, v, heads):
     B = q.shape[0]
     sp = lambda t: t.float().reshape(t.shape[0], -1, heads, 64).transpose(1, 2)

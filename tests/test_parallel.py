@@ -85,3 +85,84 @@ def test_chunk_and_frame_sharding_world2():
         assert p.exitcode == 0
     for rank, res in results:
         assert all(res.values()), (rank, res)
+
+
+def _worker_cfg3(rank, world, port, q):
+    """BASELINE configs[2]: 72 frames, max_chunk_len = 16 -> 8 overlapping chunks, ONE per rank; 24 VAE decode groups of 3 frames,
+    three per rank; C1 gather of uint8-sized frame tensors."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from star_amd.diffusion import GaussianDiffusion, noise_schedule
+        from star_amd.geometry import make_chunks
+        from star_amd.parallel import ChunkSharder, FrameSharder, gather_frames
+        sig = noise_schedule(schedule="logsnr_cosine_interp", n=1000, zero_terminal_snr=True, scale_min=2.0, scale_max=4.0)
+        gd = GaussianDiffusion(sig)
+        g = torch.Generator().manual_seed(11)
+        A = torch.randn(4, 4, generator=g) * 0.3
+        calls = []
+
+        def model(x, t, y=None, hint=None, hint_chunk=None, variant_info=None):
+            calls.append(x.shape[2])
+            h_ = hint_chunk if hint_chunk is not None else hint
+            # couples the frames of a chunk (as the 5-D GroupNorm / temporal attention do): a chunk cannot be split further
+            return torch.einsum("oc,bcfhw->bofhw", A, x) * (1.0 + 0.1 * float(y.mean())) + 0.05 * h_ + 0.01 * x.mean(dim=2, keepdim=True) + 0.001 * float(t[0])
+
+        class Noise:
+            def __init__(self, x, a, b, seed=None):
+                self.g = torch.Generator().manual_seed(99)
+                self.shape = x.shape
+
+            def __call__(self, s, sn):
+                return torch.randn(self.shape, generator=self.g)
+
+        F_, h, w = 72, 10, 8
+        noise = torch.randn(1, 4, F_, h, w, generator=g)
+        hint = torch.randn(1, 4, F_, h, w, generator=g)
+        y1, y2 = torch.randn(1, 77, 16, generator=g), torch.randn(1, 77, 16, generator=g)
+        chunks = make_chunks(F_, 0, 16)
+        res = {"eight_chunks": len(chunks) == 8 and chunks[0] == (0, 16) and chunks[-1] == (56, 72)}
+        kw = dict(noise=noise, model=model, model_kwargs=[{"y": y1}, {"y": y2}, {"hint": hint}], guide_scale=7.5, guide_rescale=0.2,
+                  solver_mode="fast", steps=50, t_max=899, t_min=0, discretization="trailing", chunk_inds=chunks, noise_sampler_cls=Noise)
+        single = gd.sample_sr(**kw)
+        n_single = len(calls)
+        calls.clear()
+        sharder = ChunkSharder()
+        sharded = gd.sample_sr(chunk_executor=sharder, **kw)
+        res["bit_identical"] = bool(torch.equal(single, sharded))
+        # 14 evaluations x 2 CFG forwards: every rank ran ONE chunk per forward, the single process all eight
+        res["one_chunk_per_rank_per_forward"] = len(calls) * world == n_single and n_single == 14 * 2 * 8 and set(calls) == {16}
+        res["plan_exchanged_once"] = len(sharder._plans) == 1
+        # VAE decode: 24 groups of 3 frames, three per rank, every rank ends with all 72 frames in order
+        z = torch.arange(F_ * 3 * 4 * 4, dtype=torch.float32).reshape(F_, 3, 4, 4)
+        groups = [(i, min(i + 3, F_)) for i in range(0, F_, 3)]
+        mine = []
+        out = FrameSharder().map_groups(groups, lambda a, b: (mine.append((a, b)), z[a:b] * 2 + 1)[1])
+        res["decode_groups"] = len(groups) == 24 and len(mine) == 3 and mine == groups[rank::world] and bool(torch.equal(out, z * 2 + 1))
+        # C1: uint8 frames [F, H, W, 3] gathered as bytes
+        clip = torch.full((F_ // world, 8, 8, 3), rank, dtype=torch.uint8)
+        allc = gather_frames(clip)
+        res["gather_u8"] = len(allc) == world and all(a.dtype == torch.uint8 and int(a.max()) == r and int(a.min()) == r for r, a in enumerate(allc))
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_cfg3_layout_on_eight_ranks():
+    """world_size 8 (gloo, CPU): the exact cfg3 layout -- 72 frames, 8 chunks of 16, one per rank in every solver evaluation, 24 decode
+    groups over 8 ranks -- reproduces the single-process sampler bit for bit (the reference's per-step chunk
+    loop: diffusion_sdedit.py:330-353)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_cfg3, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert sorted(r for r, _ in results) == list(range(8))
+    for rank, res in results:
+        assert all(res.values()), (rank, res)
