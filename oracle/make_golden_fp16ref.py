@@ -9,6 +9,9 @@ under torch.autocast(float16) -- and stores both final latents.  tests/test_pipe
 least as close to the fp32 result as the reference's own fp16 arithmetic is (plus the absolute 50 dB bar).
 Reduced width (SMALL_TEST_CONFIG) so that the CPU half-precision kernels finish in a minute; 6 frames, latent 18x16, 3 solver
 steps = 6 denoiser forwards with CFG 7.5 and rescale 0.2.
+Round 4: a third leg with bfloat16 weights under autocast(bfloat16) -- BASELINE configs[1] says "bf16", and the question whether
+ANY bf16 implementation can meet the 50 dB bar is answered by the reference's own modules in that arithmetic (it cannot: bf16 keeps 8
+mantissa bits against fp16's 11).
 """
 import os
 import sys
@@ -44,11 +47,11 @@ def main():
     noise, hint, y, neg = fp16ref_inputs()
     gd = dif.GaussianDiffusion(sigmas=sch.noise_schedule(schedule="logsnr_cosine_interp", n=1000, zero_terminal_snr=True, scale_min=2.0, scale_max=4.0))
 
-    def run(half):
+    def run(half):    # half: False (fp32) | torch.float16 | torch.bfloat16
         net = build_reference_unet(cfg).eval()
         net.load_state_dict(sd, strict=True)
         if half:
-            net = net.half()
+            net = net.to(half)
         gen = torch.Generator().manual_seed(CFG16["noise_seed"])
 
         class InjectedNoise:
@@ -62,7 +65,7 @@ def main():
 
         def model(x, t=None, y=None, hint=None, hint_chunk=None, variant_info=None):
             if half:   # what VideoToVideo_sr.test() does on the GPU: half module, autocast region (video_to_video_model.py:42,98)
-                with torch.autocast("cpu", dtype=torch.float16):
+                with torch.autocast("cpu", dtype=half):
                     return net(x, t=t, y=y, hint=hint, hint_chunk=hint_chunk, variant_info=variant_info)
             return net(x, t=t, y=y, hint=hint, hint_chunk=hint_chunk, variant_info=variant_info)
 
@@ -70,12 +73,23 @@ def main():
                             solver="dpmpp_2m_sde", solver_mode="normal", steps=CFG16["steps"], t_max=899, t_min=0, discretization="trailing",
                             chunk_inds=None).float()
 
+    path = os.path.join(ROOT, "tests", "golden", "fp16ref_small.pt")
     x32 = run(False)
-    x16 = run(True)
-    d = (x16 - x32).double()
-    rel = float(d.pow(2).mean().sqrt() / x32.double().pow(2).mean().sqrt())
-    print(f"reference fp16 (half + autocast) vs reference fp32, final latent: rel rms {rel:.3e}, range [{float(x32.min()):.2f}, {float(x32.max()):.2f}]")
-    torch.save({"cfg": CFG16, "x0_fp32": x32.clone(), "x0_ref_fp16": x16.clone()}, os.path.join(ROOT, "tests", "golden", "fp16ref_small.pt"))
+    old = torch.load(path) if os.path.isfile(path) else None
+    if old is not None and old["cfg"] == CFG16:     # round 4 adds the bf16 leg: the fp32 / fp16 tensors of round 3 stay byte for byte
+        assert torch.equal(old["x0_fp32"], x32), "the fp32 leg no longer reproduces the stored fixture"
+        x16 = old["x0_ref_fp16"]
+    else:
+        x16 = run(torch.float16)
+    xb16 = run(torch.bfloat16)    # BASELINE configs[1] names bf16: the reference's own modules with bfloat16 weights under autocast(bfloat16)
+    for name, x in (("fp16", x16), ("bf16", xb16)):
+        d = (x - x32).double()
+        rel = float(d.pow(2).mean().sqrt() / x32.double().pow(2).mean().sqrt())
+        rng = float(x32.max() - x32.min())
+        psnr = 10 * torch.log10(torch.tensor(rng ** 2) / d.pow(2).mean())
+        print(f"reference {name} (weights cast + autocast) vs reference fp32, final latent: rel rms {rel:.3e}, PSNR(range) {float(psnr):.1f} dB, "
+              f"range [{float(x32.min()):.2f}, {float(x32.max()):.2f}]")
+    torch.save({"cfg": CFG16, "x0_fp32": x32.clone(), "x0_ref_fp16": x16.clone(), "x0_ref_bf16": xb16.clone()}, path)
 
 
 if __name__ == "__main__":

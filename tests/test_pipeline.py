@@ -104,12 +104,31 @@ def test_chunked_solver_loop_with_the_hip_denoiser(width):
     assert m["psnr_range"] >= 50.0 and m["rel_rms"] <= 1.5e-2, m
 
 
+def test_no_bf16_arithmetic_meets_the_bar_the_references_own_does_not():
+    """CPU: BASELINE configs[1] says "bf16" while its parity bar says "stated fp16 tolerance (PSNR >= 50 dB vs reference output)".
+    The fixture holds the REFERENCE's own modules run in fp32, in fp16 (half + autocast, its GPU arithmetic) and in bf16 (bfloat16
+    weights + autocast(bfloat16)) on identical inputs (oracle/make_golden_fp16ref.py): its fp16 arithmetic clears 50 dB, its bf16
+    arithmetic misses it by more than 10 dB -- 8 mantissa bits against 11, three bits = 18 dB.  So f16 is the dtype that meets the
+    bar (bench.py's default) and bf16 is an opt-in speed mode on any implementation, not a gap of this one."""
+    gold = torch.load(os.path.join(ROOT, "tests", "golden", "fp16ref_small.pt"))
+    f16, b16 = parity_metrics(gold["x0_ref_fp16"], gold["x0_fp32"]), parity_metrics(gold["x0_ref_bf16"], gold["x0_fp32"])
+    print(f"the reference's own arithmetic vs its fp32 (6 forwards):  fp16 {fmt_metrics(f16)}  |  bf16 {fmt_metrics(b16)}")
+    assert f16["psnr_range"] >= 50.0 and b16["psnr_range"] <= 40.0
+    assert 6.0 <= b16["rel_rms"] / f16["rel_rms"] <= 10.0        # ~2^3: the three mantissa bits
+
+
 @pytest.mark.gpu
-def test_hip_fp16_is_as_close_to_fp32_as_the_references_own_fp16():
-    """"within a stated fp16 tolerance" (BASELINE.json): tests/golden/fp16ref_small.pt holds the final latent of the REFERENCE's own
-    UNet + sampler run twice on the CPU by oracle/make_golden_fp16ref.py -- in fp32, and with half weights under autocast(float16),
-    the arithmetic of its GPU path (video_to_video_model.py:42,98).  The HIP fp16 path on the same inputs, weights and injected
-    noise must be at least as close to the fp32 result as the reference's own fp16 result is (10 % slack), and meet the 50 dB bar."""
+def test_hip_bf16_is_as_close_to_fp32_as_the_references_own_bf16():
+    """--dtype bf16 of the HIP path against the same yardstick as the fp16 test below: at least as close to the reference's fp32
+    result as the reference's OWN bf16 arithmetic is (10 % slack).  (Neither reaches 50 dB; see the CPU test above.)"""
+    out, gold = _run_fp16ref_case(torch.bfloat16)
+    ours, theirs = parity_metrics(out, gold["x0_fp32"]), parity_metrics(gold["x0_ref_bf16"], gold["x0_fp32"])
+    print(f"final latent after 6 forwards vs the reference in fp32:  HIP bf16 path {fmt_metrics(ours)}  |  the reference's own bf16 (bfloat16 + "
+          f"autocast) {fmt_metrics(theirs)}")
+    assert torch.isfinite(out).all() and ours["rel_rms"] <= 1.1 * theirs["rel_rms"], (ours, theirs)
+
+
+def _run_fp16ref_case(dtype):
     from make_golden_fp16ref import CFG16, fp16ref_inputs
     from star_amd.diffusion import GaussianDiffusion, noise_schedule
     from star_amd.modules.unet_v2v import ControlledV2VUNet
@@ -117,7 +136,7 @@ def test_hip_fp16_is_as_close_to_fp32_as_the_references_own_fp16():
     gold = torch.load(os.path.join(ROOT, "tests", "golden", "fp16ref_small.pt"))
     assert gold["cfg"] == CFG16
     cfg = SMALL_TEST_CONFIG
-    net = ControlledV2VUNet(cfg, dtype=torch.float16, device=0)
+    net = ControlledV2VUNet(cfg, dtype=dtype, device=0)
     net.load_state_dict(random_state_dict(cfg, seed=CFG16["wseed"]))
     noise, hint, y, neg = fp16ref_inputs()
     dev = torch.device("cuda", 0)
@@ -134,6 +153,16 @@ def test_hip_fp16_is_as_close_to_fp32_as_the_references_own_fp16():
     out = gd.sample_sr(noise=noise.to(dev), model=net, model_kwargs=[{"y": y.to(dev)}, {"y": neg.to(dev)}, {"hint": hint.to(dev)}], guide_scale=7.5,
                        guide_rescale=0.2, solver="dpmpp_2m_sde", solver_mode="normal", steps=CFG16["steps"], t_max=899, t_min=0,
                        discretization="trailing", chunk_inds=None, noise_sampler_cls=Sampler).cpu()
+    return out, gold
+
+
+@pytest.mark.gpu
+def test_hip_fp16_is_as_close_to_fp32_as_the_references_own_fp16():
+    """"within a stated fp16 tolerance" (BASELINE.json): tests/golden/fp16ref_small.pt holds the final latent of the REFERENCE's own
+    UNet + sampler run twice on the CPU by oracle/make_golden_fp16ref.py -- in fp32, and with half weights under autocast(float16),
+    the arithmetic of its GPU path (video_to_video_model.py:42,98).  The HIP fp16 path on the same inputs, weights and injected
+    noise must be at least as close to the fp32 result as the reference's own fp16 result is (10 % slack), and meet the 50 dB bar."""
+    out, gold = _run_fp16ref_case(torch.float16)
     ours, theirs = parity_metrics(out, gold["x0_fp32"]), parity_metrics(gold["x0_ref_fp16"], gold["x0_fp32"])
     print(f"final latent after 6 forwards vs the reference in fp32:  HIP fp16 path {fmt_metrics(ours)}  |  the reference's own fp16 (half + "
           f"autocast) {fmt_metrics(theirs)}")
