@@ -100,3 +100,67 @@ def test_dit_model_forward(backend, dtype, emu_lib):
     assert out.shape == ref.shape == (1, T, C, H, W)
     rel = float((out - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
     assert torch.isfinite(out).all() and rel <= (6e-3 if dtype == torch.float16 else 4e-2), f"DiT forward rel rms {rel:.3e}"
+
+
+FULL_GEOM = (226, 7, 30, 45)    # 226 text tokens + 7 x 30 x 45 = 9450 video tokens = 9676: CogVideoX-5B's sequence
+
+
+@pytest.mark.gpu
+def test_dit_block_at_its_real_size():
+    """ONE block at CogVideoX-5B's real size -- hidden 3072, 48 heads, 226 text + 9450 video = 9676 tokens -- against the fp32
+    restatement run on the host cores (3.4 TFLOP: the CPU flash kernel keeps the 48 x 9676^2 logits out of memory): AdaLNMixin.layer_forward
+    (cogvideox-based/sat/dit_video_concat.py:482-598) with LIEM (cogvideox-based/transformer.py:316-348,485-486).  Everything above
+    hidden 1024 had only been timed, never compared."""
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    cfg = O.DitConfig(hidden=3072, heads=48, time_embed_dim=512, n_layers=1)
+    rel = _run("hip", torch.float16, None, cfg, FULL_GEOM, 0, 4e-3)
+    print(f"DiT block at full size (hidden 3072, 48 heads, 9676 tokens): rel rms {rel:.2e}")
+
+
+def _aliased_model_state_dict(cfg_two, n_layers, **kw):
+    """a full-depth state dict whose layers 2.. alias the tensors of layers 0 / 1 (host memory of two layers instead of 19 GB)"""
+    sd = O.random_dit_model_state_dict(cfg_two, **kw)
+    out = dict(sd)
+    for i in range(2, n_layers):
+        src = i % 2
+        for k, v in sd.items():
+            for pat in (f"transformer.layers.{src}.", f"adaLN_modulations.{src}.1.", f"query_layernorm_list.{src}.", f"key_layernorm_list.{src}."):
+                if pat in k:
+                    out[k.replace(pat, pat.replace(f"{src}.", f"{i}.", 1) if pat.startswith("transformer") else pat.replace(f".{src}.", f".{i}."))] = v
+    return out
+
+
+@pytest.mark.gpu
+def test_dit_forward_at_full_size():
+    """`DiffusionTransformer.forward` (dit_video_concat.py:791-817) at CogVideoX-5B's full width and sequence length: (a) TWO layers
+    end to end -- timestep embedding, K = 128 patch embedding of the (latent | LQ latent) pair, 4096-wide text projection, the
+    blocks, both final LayerNorms at hidden 3072, adaLN, Linear, unpatchify -- against the fp32 restatement on the host; (b) the
+    full depth of 42 layers once: finite, the right shape, not degenerate (layers 2.. reuse the weights of layers 0 / 1 so that the
+    host side stays at two layers of random numbers)."""
+    from star_amd.modules.dit import DiffusionTransformer
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    C, p, th = 16, 2, 4096
+    n_text, T, h, w = FULL_GEOM
+    H, W = h * p, w * p
+    cfg2 = O.DitConfig(hidden=3072, heads=48, time_embed_dim=512, n_layers=2)
+    sd = O.random_dit_model_state_dict(cfg2, in_channels=C, out_channels=C, patch=p, text_hidden=th, seed=0)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, T, 2 * C, H, W, generator=g)
+    ctxt = torch.randn(1, n_text, th, generator=g)
+    ts = torch.tensor([417.0])
+    net = DiffusionTransformer(cfg2.hidden, cfg2.heads, cfg2.time_embed_dim, 2, in_channels=C, out_channels=C, patch_size=p, text_hidden=th,
+                               ln_eps=cfg2.ln_eps, dtype=torch.float16).load_state_dict(sd)
+    dev = net.blocks.ctx.torch_device
+    out = net(x.to(dev), ts.to(dev), ctxt.to(dev)).float().cpu()
+    ref = O.dit_forward(sd, cfg2, x.half().float(), ts, ctxt.half().float(), C, p)
+    rel = float((out - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+    print(f"DiT forward, 2 layers at full width / 9676 tokens: rel rms {rel:.2e}")
+    assert out.shape == ref.shape == (1, T, C, H, W) and torch.isfinite(out).all() and rel <= 6e-3, rel
+    net.blocks.ctx.close()
+    del net
+    full = _aliased_model_state_dict(cfg2, 42, in_channels=C, out_channels=C, patch=p, text_hidden=th, seed=0)
+    deep = DiffusionTransformer(3072, 48, 512, 42, in_channels=C, out_channels=C, patch_size=p, text_hidden=th, dtype=torch.float16).load_state_dict(full)
+    o42 = deep(x.to(dev), ts.to(dev), ctxt.to(dev)).float().cpu()
+    print(f"DiT forward, 42 layers at full size: std {float(o42.std()):.3f}, max |.| {float(o42.abs().max()):.2f}")
+    assert o42.shape == (1, T, C, H, W) and torch.isfinite(o42).all() and 1e-3 < float(o42.std()) < 1e3
+    assert float((o42 - out).abs().mean()) > 1e-3          # forty more layers did something
