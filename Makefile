@@ -20,15 +20,16 @@ emu: tools/hostemu/libstar_emu.so
 build/hip/attn.o: HIPFLAGS += -fno-honor-nans -fno-slp-vectorize
 build/hip/attn7.o: HIPFLAGS += -fno-honor-nans -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form
 build/hip/gemm_as.o: HIPFLAGS += -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form
-build/hip/%.o: $(CSRC)/%.cpp $(wildcard $(CSRC)/*.h) include/star_hip.h
+# precise header dependencies (-MMD): touching norm.h no longer recompiles the GEMM instantiation units (minutes each)
+build/hip/%.o: $(CSRC)/%.cpp
 	@mkdir -p build/hip
-	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+	$(HIPCC) $(HIPFLAGS) -MMD -MP -c $< -o $@
 star_amd/libstar_hip.so: $(HIP_OBJS)
 	$(HIPCC) --offload-arch=gfx950 -shared -fPIC $^ -o $@
 
-build/emu/%.o: $(CSRC)/%.cpp $(wildcard $(CSRC)/*.h) include/star_hip.h
+build/emu/%.o: $(CSRC)/%.cpp
 	@mkdir -p build/emu
-	$(CLANGXX) $(EMUFLAGS) -c $< -o $@
+	$(CLANGXX) $(EMUFLAGS) -MMD -MP -c $< -o $@
 build/emu/hostemu.o: tools/hostemu/hostemu.cpp $(CSRC)/hostemu.h
 	@mkdir -p build/emu
 	$(CLANGXX) $(EMUFLAGS) -c $< -o $@
@@ -41,12 +42,14 @@ bench: tools/bench/libstar_hip_bench.so
 build/bench/attn.o: HIPFLAGS += -fno-honor-nans -fno-slp-vectorize
 build/bench/attn7.o: HIPFLAGS += -fno-honor-nans -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form
 build/bench/gemm_as.o: HIPFLAGS += -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form
-build/bench/%.o: $(CSRC)/%.cpp $(wildcard $(CSRC)/*.h) include/star_hip.h
+build/bench/%.o: $(CSRC)/%.cpp
 	@mkdir -p build/bench
-	$(HIPCC) $(HIPFLAGS) -DSTAR_BENCH_VARIANTS=1 -c $< -o $@
+	$(HIPCC) $(HIPFLAGS) -DSTAR_BENCH_VARIANTS=1 -MMD -MP -c $< -o $@
 tools/bench/libstar_hip_bench.so: $(BENCH_OBJS)
 	@mkdir -p tools/bench
 	$(HIPCC) --offload-arch=gfx950 -shared -fPIC $^ -o $@
+
+-include $(wildcard build/hip/*.d build/emu/*.d build/bench/*.d)
 
 clean:
 	rm -rf build star_amd/libstar_hip.so tools/hostemu/libstar_emu.so tools/bench

@@ -52,6 +52,9 @@ int star_has_bench_variants(void);                       /* 1 only in builds wit
 int star_pool_trim(star_ctx* ctx);
 size_t star_pool_bytes(star_ctx* ctx);
 size_t star_pool_peak_bytes(star_ctx* ctx);
+/* diagnostic: how many star_gemm / internal GEMM launches of this context were split into full rounds of big tiles + a remainder of
+ * 128 x 128 tiles (see star_gemm_desc.force_tile) */
+int64_t star_gemm_split_count(star_ctx* ctx);
 
 /* ---- kernel-level entry points (unit parity; each is one HIP kernel family) */
 typedef struct star_gemm_desc {
@@ -63,7 +66,11 @@ typedef struct star_gemm_desc {
   int32_t up_crop;                   /* STAR_A_CONV3X3_UP: rows cropped top+bottom after the 2x upsample (1 UNet, 0 VAE) */
   int32_t epi;                       /* STAR_EPI_* */
   int32_t force_tile;                /* 0 = auto; 1 256x256, 2 256x320, 3 128x128, 4 256x128, 9 2 x (128x256), 30 the A-stationary K = 320 kernel
-                                        (gemm_as.h: plain A, STAR_EPI_ROWAFF layers); anything else: bench build only */
+                                        (gemm_as.h: plain A, STAR_EPI_ROWAFF layers); 1000 + n = automatic choice with the tile rounds balanced
+                                        for n compute units instead of the device's (the launcher gives a poorly filled last round of big
+                                        tiles to a second launch of 128 x 128 tiles); 18 the persistent one-wave-per-SIMD tile (gemm_p.h:
+                                        plain A, 16-bit output, bias / residual / STAR_EPI_ROWAFF), 2000 + n the same on n resident workgroups;
+                                        anything else: bench build only */
   const float* rowab;                /* STAR_EPI_ROWAFF (a LayerNorm folded into this projection, unet_v2v.py:448-450 + the Linear behind it): */
   const float* colsum;               /*   out = a_m * acc + b_m * colsum[n] + bias[n], (a_m, b_m) = rowab[m] fp32 pairs, colsum fp32 [N]; else null */
 } star_gemm_desc;

@@ -74,6 +74,7 @@ int star_ctx_create(int device_id, int dtype, star_ctx** out) {
   rt::memset_async(z, 0, 256, nullptr);
   rt::stream_sync(nullptr);
   h->c.zero_page = z;
+  h->c.num_cus = rt::device_cu_count(device_id);
   *out = h;
   return 0;
 }
@@ -115,6 +116,7 @@ int star_pool_trim(star_ctx* h) {   // return the cached (free) blocks to the dr
 }
 size_t star_pool_bytes(star_ctx* h) { return h->c.pool.total(); }
 size_t star_pool_peak_bytes(star_ctx* h) { return h->c.pool.peak(); }
+int64_t star_gemm_split_count(star_ctx* h) { return h ? (int64_t)h->c.gemm_splits : 0; }
 
 int star_gemm(star_ctx* h, const star_gemm_desc* d) {
   if (h) rt::set_device(h->c.device);   // follow the context's device, not the caller's current one
@@ -124,6 +126,8 @@ int star_gemm(star_ctx* h, const star_gemm_desc* d) {
   a.mode = d->mode; a.H = d->H; a.Wd = d->Wd; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo;
   a.stride = d->stride; a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.HW = d->HW; a.F = d->F; a.up_crop = d->up_crop;
   a.epi = d->epi; a.force_tile = d->force_tile; a.rowab = d->rowab; a.colsum = d->colsum;
+  if (a.force_tile >= 2000) { a.assume_cus = a.force_tile - 2000; a.force_tile = 18; }   // the persistent tile on that many resident workgroups (tests)
+  else if (a.force_tile >= 1000) { a.assume_cus = a.force_tile - 1000; a.force_tile = 0; }   // automatic choice, rounds balanced for that many CUs (tests)
   return finish(h, op_gemm(&h->c, a));
 }
 

@@ -41,6 +41,8 @@ struct GemmParams {
   int epi;
   int tiles_m, tiles_n;
   int group_m;   // > 1: the tile walk runs column-major inside groups of group_m tile rows (see the kernel)
+  int m_off;     // first output row of this launch (a multiple of the tile height): the launcher may give the last, partly filled round
+                 // of big tiles to a second launch of small tiles (gemm_impl.h: tail split); tiles_m counts the rows from m_off on
   // EPI_ROWAFF (LayerNorm folded into this GEMM): out = a_m * acc + b_m * s_n + c_n with (a_m, b_m) = rowab[m], s_n = colsum[n],
   // c_n = bias[n]
   const float* rowab;   // [M][2]
@@ -120,7 +122,7 @@ gemm_kernel(const GemmParams p) {
     tile_m = g * p.group_m + in % rows;
     tile_n = in / rows;
   }
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int m0 = p.m_off + tile_m * BM, n0 = tile_n * BN;
 
   if constexpr (!F32OUT) {   // this tile's bias slice, read from LDS in the epilogue (visible after the main loop's barriers)
     float* bl = reinterpret_cast<float*>(smem + SMEM_LOOP);

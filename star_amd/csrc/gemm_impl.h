@@ -17,7 +17,8 @@ static int launch_gemm_f(Ctx* ctx, const GemmArgs& a) {
   p.H = a.H; p.Wd = a.Wd; p.Cin = a.Cin; p.Ho = a.Ho; p.Wo = a.Wo; p.stride = a.stride; p.pad_t = a.pad_t; p.pad_l = a.pad_l;
   p.HW = a.HW; p.F = a.F; p.up_crop = a.up_crop; p.epi = a.epi;
   p.rowab = a.rowab; p.colsum = a.colsum;
-  p.tiles_m = (a.M + BM - 1) / BM;
+  p.m_off = a.m_off;
+  p.tiles_m = ((a.m_end > 0 ? a.m_end : a.M) - a.m_off + BM - 1) / BM;
   p.tiles_n = (a.N + BN - 1) / BN;
   p.group_m = a.group_m >= 0 ? a.group_m : (p.tiles_n >= 12 ? 8 : 1);   // auto: where a row of tiles is wide (measured +3-11 %, 8192^3 1140 -> 1233 TF/s; narrower rows lose 0-4 %: profiles/r03_gemm_group_ab.txt)
   // 2 stages x 64 k, or PIPE ring slots x 32 k; never less than the epilogue's per-wave staging blocks
@@ -72,6 +73,9 @@ static int launch_gemm_t(Ctx* ctx, const GemmArgs& a) {
   return launch_gemm_f<T, BM, BN, WM, WN, MINW, false, STAGGER, PIPE, ALLEPI>(ctx, a);
 }
 
+int launch_gemm_persist(Ctx* ctx, const GemmArgs& a);   // gemm_p.cpp
+bool gemm_persist_covers(const GemmArgs& a);
+
 #ifdef STAR_BENCH_VARIANTS
 static bool no_sched_env() { return std::getenv("STAR_NO_SCHED") != nullptr; }
 #else
@@ -104,6 +108,35 @@ static int launch_gemm(Ctx* ctx, const GemmArgs& a) {
     else if (a.N <= 128) tile = 4;
     else tile = 1;
   }
+  // ---- tail split.  The big tiles run ONE workgroup per CU, so a launch is ceil(tiles / CUs) rounds and the last round can be mostly
+  // empty: the 1280-wide layers of level 2 (M = 55296: 864 tiles of 256 x 320 = 3.4 rounds, 1080 of 256 x 256 = 4.2) spent 16 % of
+  // their time with three quarters of the chip idle.  When the last round is poorly filled, the launch covers only the tile rows of
+  // the FULL rounds and the remaining rows go to a second launch of 128 x 128 tiles (tile 3: two workgroups per CU, every mode and
+  // epilogue flavour, same k order per output -- bit-identical).  Decided by a cost model in units of one big tile's time.
+  if (!a.force_tile && a.m_off == 0 && a.m_end == 0 && (tile == 1 || tile == 2 || tile == 17 || tile == 18)) {
+    const int cus = a.assume_cus > 0 ? a.assume_cus : (ctx->num_cus > 0 ? ctx->num_cus : 256);
+    const int bm = 256, bn = tile == 2 ? 320 : 256;
+    const long long tm = (a.M + bm - 1) / bm, tn = (a.N + bn - 1) / bn, nt = tm * tn;
+    const long long full = nt / cus;                      // full rounds
+    if (full >= 1 && nt % cus != 0) {
+      const long long main_rows_t = full * cus / tn;      // tile rows of the main launch (its tiles fit `full` rounds)
+      const long long rem_rows = a.M - main_rows_t * bm;
+      const long long ns = ((rem_rows + 127) / 128) * ((a.N + 127) / 128);
+      const double small_work = 128.0 * 128.0 / ((double)bm * bn);          // one small tile in units of a big one
+      double rem_t = (double)ns * small_work / cus;                         // remainder work per CU ...
+      if (rem_t < small_work) rem_t = small_work;                           // ... never less than one small tile
+      rem_t /= 0.6;                                                         // the 128 x 128 tiles run at ~0.6 of the big tiles' rate
+      const double t_split = (double)((main_rows_t * tn + cus - 1) / cus) + rem_t, t_plain = (double)((nt + cus - 1) / cus);
+      if (main_rows_t >= 1 && rem_rows > 0 && t_split < 0.95 * t_plain) {
+        GemmArgs m = a, r = a;
+        m.force_tile = tile; m.m_end = (int)(main_rows_t * bm);
+        r.force_tile = 3; r.m_off = (int)(main_rows_t * bm);
+        ++ctx->gemm_splits;
+        if (int rc = launch_gemm<T>(ctx, m)) return rc;
+        return launch_gemm<T>(ctx, r);
+      }
+    }
+  }
   switch (tile) {
     // 8 waves per workgroup (2 per SIMD, <= 256 VGPRs each; 192 / 236 used, no spills): measured 1.3-3.6x faster than
     // 4-wave variants of the same tiles on the K = 320 layers (profiles/r01_gemm_tile_sweep.txt)
@@ -113,6 +146,7 @@ static int launch_gemm(Ctx* ctx, const GemmArgs& a) {
     case 17:
       if (a.epi & (EPI_OUT_F32 | EPI_ROWAFF | EPI_GELU_TANH | EPI_GEGLU)) return ctx->fail("gemm: tile 17 has the plain and residual 16-bit epilogues only");
       return launch_gemm_f<T, 256, 256, 2, 2, 1, false, false, 0, false, 1>(ctx, a);
+    case 18: return launch_gemm_persist(ctx, a);   // persistent one-wave-per-SIMD tile with a wave-private epilogue (gemm_p.h)
     case 3: return launch_gemm_t<T, 128, 128, 2, 2, 2, false, 0, true>(ctx, a);
     case 4: return launch_gemm_t<T, 256, 128, 4, 1, 1, false, 0, true>(ctx, a);
 #ifdef STAR_BENCH_VARIANTS   // A/B experiments of round 1 / 2 that lost to the tiles above (profiles/r01_gemm_ablation.txt, r02_gemm8_ablation.txt)

@@ -156,6 +156,37 @@ STAR_GLOBAL void gn_apply_kernel(const GnApplyParams p) {
   for (; r < r1; r += RL) one(r, *reinterpret_cast<const vec<T, 8>*>(xb + (size_t)r * p.ldx));
 }
 
+// ------------------------------------------------------------------ GroupNorm folded into the Linear behind it
+// A whole-chunk (5-D) GroupNorm WITHOUT activation that feeds only a Linear / Conv1d(k=1) -- TemporalTransformer.norm -> proj_in
+// (unet_v2v.py:1002-1005, 1052-1060) -- is an affine map per CHANNEL with one (a_c, b_c) for all rows (batch 1):
+//   proj_in(GN(x))[m][n] = sum_c W[n][c] (a_c x[m][c] + b_c) + bias[n] = (x W'^T)[m][n] + bias'[n],
+//   W'[n][c] = W[n][c] a_c (rounded to T),  bias'[n] = bias[n] + sum_c W[n][c] b_c.
+// The statistics pass stays; the apply pass (one read + one write of the activation) and the normalised tensor disappear: the
+// projection reads x itself.  One block per output row n; ab = the finalize kernel's per-channel pairs.
+struct GnFoldParams {
+  const void* W; const float* bias; const float* ab; void* Wout; float* bias_out; int N, K;
+};
+template <class T>
+STAR_GLOBAL void gn_fold_weights_kernel(const GnFoldParams p) {
+  float* red = reinterpret_cast<float*>(dyn_smem());   // [blockDim.x]
+  const int n = blockIdx.x, t = threadIdx.x;
+  const T* __restrict__ w = (const T*)p.W + (size_t)n * p.K;
+  T* __restrict__ wo = (T*)p.Wout + (size_t)n * p.K;
+  float acc = 0.f;
+  for (int k = t; k < p.K; k += blockDim.x) {
+    const float wv = to_f32<T>(w[k]);
+    wo[k] = from_f32<T>(wv * p.ab[2 * k]);
+    acc += wv * p.ab[2 * k + 1];
+  }
+  red[t] = acc;
+  block_sync();
+  if (t == 0) {   // fixed order: reproducible
+    float sum = 0.f;
+    for (int i = 0; i < (int)blockDim.x; ++i) sum += red[i];
+    p.bias_out[n] = sum + (p.bias ? p.bias[n] : 0.f);
+  }
+}
+
 // ------------------------------------------------------------------ LayerNorm rows (+ LIEM gates)
 // reference: BasicTransformerBlock.norm1/2/3 (unet_v2v.py:448-450), LIEM SpatialAttention (:380-394)
 //            and TemporalLocalAttention (:396-411) applied in front of norm1 / norm2 (:466-490).

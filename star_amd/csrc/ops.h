@@ -32,6 +32,8 @@ struct GemmArgs {
   const float* rowab = nullptr; const float* colsum = nullptr;   // EPI_ROWAFF operands
   int group_m = -1;    // tile walk: -1 auto, 0 / 1 row-major, n column-major inside groups of n tile rows (gemm.h)
   int persist = 0;     // > 0: at most this many workgroups walk the output tiles (multiple of 8); 0 = one workgroup per tile
+  int m_off = 0, m_end = 0;   // internal (tail split, gemm_impl.h): this launch covers output rows [m_off, m_end) of the M rows (m_end 0 = M)
+  int assume_cus = 0;         // > 0: balance the tile rounds for this many compute units instead of the device's (tests)
 };
 int op_gemm(Ctx* ctx, const GemmArgs& a);
 
@@ -62,6 +64,11 @@ int op_temporal_attn(Ctx* ctx, const TAttnArgs& a);
 // GroupNorm(32 groups) over channels-last rows; rows_per_stat = H*W (per frame) or F*H*W (whole chunk)
 int op_group_norm(Ctx* ctx, const void* x, int ldx, void* y, int ldy, const float* gamma, const float* beta,
                   int rows, int C, int rows_per_stat, float eps, bool silu);
+// statistics + finalize of a GroupNorm only: ab[nstat][C][2] = the per-channel affine pairs (y = x * a + b); nothing is applied
+int op_group_norm_stats(Ctx* ctx, const void* x, int ldx, const float* gamma, const float* beta, int rows, int C, int rows_per_stat,
+                        float eps, float* ab);
+// a whole-chunk GroupNorm folded into the Linear behind it (norm.h): Wout[n][k] = W[n][k] * ab[k][0], bias_out[n] = bias[n] + sum_k W[n][k] * ab[k][1]
+int op_gn_fold_weights(Ctx* ctx, const void* W, const float* bias, const float* ab, void* Wout, float* bias_out, int N, int K);
 int op_layer_norm(Ctx* ctx, const void* x, int ldx, void* y, int ldy, const float* gamma, const float* beta,
                   int rows, int C, float eps, int mode, const float* gate_w, float* maps, int H, int W, float* rowab = nullptr);
 int op_concat_add(Ctx* ctx, const void* a, const void* b, const void* c, void* out, int rows, int C1, int C2);

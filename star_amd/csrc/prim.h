@@ -351,6 +351,48 @@ STAR_DEV void glds16_buf(BufRsrc r, uint32_t voff, void* lds_wave_base) {
 constexpr uint32_t GLDS_BUF_RANGE = 0xFFFF0000u;   // descriptor range used by the gathers: every valid offset is below it ...
 constexpr uint32_t GLDS_BUF_OOB = 0xFFFFFFF0u;     // ... and this one is outside (reads as zeros)
 
+// A hand-built buffer descriptor for LDS-DMA that must stay INVISIBLE to hipcc's vmcnt bookkeeping (the persistent GEMM of
+// gemm_p.h keeps a hand-counted DMA stream running across output tiles): base and bytes wave-uniform, raw addressing (stride 0).
+// A lane whose byte offset voff is >= bytes writes ZEROS to its LDS slot and touches no memory; soff is a wave-uniform extra
+// offset (the K tile) that stays inside a row, so rows at or past the end of the matrix are out of range whether or not the
+// hardware counts soff in the check.
+#ifdef STAR_HOSTEMU
+struct BufDesc { const char* base; uint32_t bytes; };
+STAR_DEV BufDesc make_desc(const void* base, uint32_t bytes) { return BufDesc{(const char*)base, bytes}; }
+STAR_DEV void glds16_desc(BufDesc d, uint32_t voff, uint32_t soff, void* lds_wave_base) {
+  struct P { void* dst; } mine{lds_wave_base};
+  (void)::star_emu::wave_exchange(&mine, sizeof(mine));
+  u32x4 v = {0u, 0u, 0u, 0u};
+  if ((uint64_t)voff + 16 <= d.bytes) memcpy(&v, d.base + soff + voff, 16);
+  memcpy((char*)lds_wave_base + lane_id() * 16, &v, 16);
+}
+STAR_DEV void glds4_desc(BufDesc d, uint32_t voff, uint32_t soff, void* lds_wave_base) {
+  struct P { void* dst; } mine{lds_wave_base};
+  (void)::star_emu::wave_exchange(&mine, sizeof(mine));
+  uint32_t v = 0;
+  if ((uint64_t)voff + 4 <= d.bytes) memcpy(&v, d.base + soff + voff, 4);
+  memcpy((char*)lds_wave_base + lane_id() * 4, &v, 4);
+}
+#else
+using BufDesc = u32x4;
+STAR_DEV BufDesc make_desc(const void* base, uint32_t bytes) {
+  const uint64_t b = (uint64_t)(uintptr_t)base;
+  BufDesc d;
+  d[0] = (uint32_t)b; d[1] = (uint32_t)(b >> 32) & 0xffffu; d[2] = bytes; d[3] = 0x00020000u;
+  return d;
+}
+STAR_DEV void glds16_desc(BufDesc d, uint32_t voff, uint32_t soff, void* lds_wave_base) {
+  const uint32_t lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds_wave_base;
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :: "s"(lds), "v"(voff), "s"(d), "s"(soff) : "memory", "m0");
+}
+STAR_DEV void glds4_desc(BufDesc d, uint32_t voff, uint32_t soff, void* lds_wave_base) {   // 4 bytes per lane (bias slices)
+  const uint32_t lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds_wave_base;
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
+               :: "s"(lds), "v"(voff), "s"(d), "s"(soff) : "memory", "m0");
+}
+#endif
+
 // ---------------------------------------------------------------- transpose read
 // ds_read_b64_tr_b16: every lane passes the (8-byte aligned) LDS address of 4
 // contiguous 16-bit elements P[lane][0..3]; within each 16-lane group lane i

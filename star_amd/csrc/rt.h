@@ -18,6 +18,7 @@ inline int stream_sync(hipStream_t) { return 0; }
 inline int set_device(int) { return 0; }
 inline int device_count() { return 1; }
 inline bool device_is_gfx950(int) { return true; }
+inline int device_cu_count(int) { return 256; }
 inline const char* last_error_string() { return "hostemu"; }
 inline int peek_error() { return 0; }
 inline void* event_record(hipStream_t) { return nullptr; }
@@ -52,6 +53,11 @@ inline bool device_is_gfx950(int d) {
   hipDeviceProp_t pr;
   if (hipGetDeviceProperties(&pr, d) != hipSuccess) return false;
   return strncmp(pr.gcnArchName, "gfx950", 6) == 0 && pr.sharedMemPerBlockOptin >= 160 * 1024;
+}
+inline int device_cu_count(int d) {
+  hipDeviceProp_t pr;
+  if (hipGetDeviceProperties(&pr, d) != hipSuccess || pr.multiProcessorCount <= 0) return 256;
+  return pr.multiProcessorCount;
 }
 inline int peek_error() { return hipPeekAtLastError() != hipSuccess; }
 inline void* event_record(hipStream_t s) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; (void)hipEventRecord(e, s); return (void*)e; }

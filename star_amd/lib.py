@@ -103,6 +103,7 @@ class Library:
         self.pool_trim = _sig(c, "star_pool_trim", i32, vp)
         self.pool_bytes = _sig(c, "star_pool_bytes", sz, vp)
         self.pool_peak_bytes = _sig(c, "star_pool_peak_bytes", sz, vp)
+        self.gemm_split_count = _sig(c, "star_gemm_split_count", i64, vp)
         self.gemm = _sig(c, "star_gemm", i32, vp, ctypes.POINTER(GemmDesc))
         f32 = ctypes.c_float
         self.attn_fwd = _sig(c, "star_attn_fwd", i32, vp, ctypes.POINTER(AttnDesc))

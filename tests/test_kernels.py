@@ -37,7 +37,7 @@ def dev(ctx, t):
     return t.to(ctx.torch_device)
 
 
-PRODUCT_TILES = (0, 1, 2, 3, 4, 9, 10, 17, 30)
+PRODUCT_TILES = (0, 1, 2, 3, 4, 9, 10, 17, 18, 30)
 
 
 _BENCH_CTX = {}
@@ -182,6 +182,106 @@ def test_temporal_conv(ctx, dtype, Fr, H, Wd, C):
     wp = w[:, :, :, 0, 0].permute(0, 2, 1).reshape(C, 3 * C).contiguous()
     out = ctx.gemm(dev(ctx, a), dev(ctx, wp), bias=dev(ctx, b), res=dev(ctx, res), mode=L.A_TCONV3, temporal=(Fr, H * Wd, C))
     assert_close(out, ref, dtype, what="tconv")
+
+
+@pytest.mark.parametrize("M,N,K,wgs", [(515, 512, 256, 0), (300, 264, 64, 0), (700, 600, 192, 2), (257, 1288, 128, 3), (1030, 256, 448, 1), (64, 8, 64, 0),
+                                        (2100, 1920, 640, 8)])
+def test_gemm_persistent_tile(ctx, dtype, M, N, K, wgs):
+    """tile 18 (gemm_p.h): resident workgroups walk their output tiles, the K tiles of all of them form one LDS-DMA stream (operands
+    through hand-built buffer descriptors: ragged rows / columns read as zeros), zero-C MFMAs open a tile, wave-private epilogue.
+    Bias / residual / folded-LayerNorm flavours against fp32 and BIT FOR BIT against the 8-wave tile (same k order per output);
+    `wgs` resident workgroups (force_tile 2000 + n) so that a workgroup streams across several output tiles, with odd and single K
+    tile counts and ragged edges; GEGLU / fp32 output are refused."""
+    if M * N * K > 6e8 and ctx.lib.is_hostemu:
+        pytest.skip("hardware-only size")
+    g = torch.Generator().manual_seed(M + 3 * N + K)
+    A = torch.randn(M, K, generator=g).to(dtype)
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dtype)
+    b = torch.randn(N, generator=g)
+    R = torch.randn(M, N, generator=g).to(dtype)
+    rowab = torch.stack([torch.rand(M, generator=g) + 0.5, torch.randn(M, generator=g)], dim=1).contiguous()
+    colsum = W.float().sum(1).contiguous()
+    Ad, Wd_, bd, Rd = dev(ctx, A), dev(ctx, W), dev(ctx, b), dev(ctx, R)
+    ft = 2000 + wgs if wgs else 18
+    acc = A.float() @ W.float().T
+    for kw, ref in ((dict(bias=bd), acc + b), (dict(), acc), (dict(bias=bd, res=Rd), acc + b + R.float()),
+                    (dict(bias=bd, rowab=dev(ctx, rowab), colsum=dev(ctx, colsum)), rowab[:, :1] * acc + rowab[:, 1:] * colsum[None] + b[None])):
+        out = ctx.gemm(Ad, Wd_, force_tile=ft, **kw)
+        assert torch.equal(out, ctx.gemm(Ad, Wd_, force_tile=1, **kw)), kw.keys()
+        assert_close(out, ref, dtype, scale=6.0, what=f"gemm tile 18 {list(kw)}")
+    with pytest.raises(L.StarError):
+        ctx.gemm(Ad, Wd_, bias=bd, out_f32=True, force_tile=18)
+    if N % 64 == 0:
+        with pytest.raises(L.StarError):
+            ctx.gemm(Ad, Wd_, bias=bd, geglu=True, force_tile=18)
+
+
+def test_gemm_tail_split_is_bit_identical(ctx, dtype):
+    """The launcher gives a poorly filled LAST ROUND of big tiles (one workgroup per CU) to a second launch of 128 x 128 tiles over
+    the remaining rows (gemm_impl.h: tail split; the kernel's m_off).  force_tile = 1000 + n balances the rounds for n CUs, so small
+    problems split: plain / residual / GEGLU / folded-LayerNorm / fp32-output epilogues, the 3x3 conv (stride 1 and the stride-2
+    Downsample) and the temporal conv -- whose gathers derive (frame, y, x) from the absolute row -- all bit-identical to the
+    unsplit launch."""
+    g = torch.Generator().manual_seed(91)
+    n0 = ctx.lib.gemm_split_count(ctx.h)
+    # plain A, 256 x 320 tiles (N = 1280: 4 tile columns): 3 x 4 tiles on "8 CUs" -> 2 tile rows in one full round + 88 rows of small tiles
+    M, N, K = 600, 1280, 128
+    A = torch.randn(M, K, generator=g).to(dtype)
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dtype)
+    b = torch.randn(N, generator=g)
+    R = torch.randn(M, N, generator=g).to(dtype)
+    Ad, Wd_, bd, Rd = dev(ctx, A), dev(ctx, W), dev(ctx, b), dev(ctx, R)
+    whole = ctx.gemm(Ad, Wd_, bias=bd, res=Rd, force_tile=2)
+    assert ctx.lib.gemm_split_count(ctx.h) == n0                    # a forced tile is never split
+    split = ctx.gemm(Ad, Wd_, bias=bd, res=Rd, force_tile=1008)
+    assert ctx.lib.gemm_split_count(ctx.h) == n0 + 1                # ... the automatic choice on "8 CUs" is
+    assert torch.equal(whole, split)
+    assert_close(split, A.float() @ W.float().T + b + R.float(), dtype, what="gemm tail split")
+    # 256 x 256 tiles (N = 1536: 6 tile columns), GEGLU, the folded LayerNorm, both, fp32 output
+    M, N, K = 600, 1536, 64
+    A = torch.randn(M, K, generator=g).to(dtype)
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dtype)
+    b = torch.randn(N, generator=g)
+    rowab = torch.stack([torch.rand(M, generator=g) + 0.5, torch.randn(M, generator=g)], dim=1).contiguous()
+    colsum = W.float().sum(1).contiguous()
+    Ad, Wd_, bd = dev(ctx, A), dev(ctx, W), dev(ctx, b)
+    for kw in (dict(geglu=True), dict(rowab=dev(ctx, rowab), colsum=dev(ctx, colsum)), dict(geglu=True, rowab=dev(ctx, rowab), colsum=dev(ctx, colsum)), dict(out_f32=True)):
+        whole = ctx.gemm(Ad, Wd_, bias=bd, force_tile=1, **kw)
+        split = ctx.gemm(Ad, Wd_, bias=bd, force_tile=1008, **kw)
+        assert torch.equal(whole, split), kw
+    # gathered modes, 64 -> 192 channels (256 x 256 tiles, one tile column), > 4096 rows so that the big tiles are the automatic choice
+    NB, Cin, H, Wd, Cout = 10, 64, 22, 20, 192                        # 4400 rows: 18 tile rows on "8 CUs" -> 16 + 304 rows
+    x = torch.randn(NB, Cin, H, Wd, generator=g).to(dtype)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)).to(dtype)
+    b = torch.randn(Cout, generator=g)
+    wp = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous()
+    xr, wpd, bd = dev(ctx, nhwc_rows(x)), dev(ctx, wp), dev(ctx, b)
+    ref = F.conv2d(x.float(), w.float(), b, padding=1)
+    whole = ctx.gemm(xr, wpd, bias=bd, mode=L.A_CONV3X3, conv=(NB, H, Wd, Cin, H, Wd, 1, 1, 1), force_tile=1)
+    split = ctx.gemm(xr, wpd, bias=bd, mode=L.A_CONV3X3, conv=(NB, H, Wd, Cin, H, Wd, 1, 1, 1), force_tile=1008)
+    assert torch.equal(whole, split)
+    assert_close(split, nhwc_rows(ref), dtype, what="conv3x3 tail split")
+    x4 = torch.randn(35, Cin, H, Wd, generator=g).to(dtype)           # Downsample: 35 frames -> 35 x 12 x 10 = 4200 output rows
+    ref = F.conv2d(x4.float(), w.float(), b, stride=2, padding=(2, 1))
+    Ho, Wo = ref.shape[2:]
+    x4r = dev(ctx, nhwc_rows(x4))
+    whole = ctx.gemm(x4r, wpd, bias=bd, mode=L.A_CONV3X3, conv=(35, H, Wd, Cin, Ho, Wo, 2, 2, 1), force_tile=1)
+    split = ctx.gemm(x4r, wpd, bias=bd, mode=L.A_CONV3X3, conv=(35, H, Wd, Cin, Ho, Wo, 2, 2, 1), force_tile=1008)
+    assert torch.equal(whole, split)
+    assert_close(split, nhwc_rows(ref), dtype, what="conv3x3 s2 tail split")
+    Fr, C = 22, 192                                                  # temporal conv: 22 frames of 14 x 14 = 4312 rows
+    xt = torch.randn(1, C, Fr, 14, 14, generator=g).to(dtype)
+    wt = (torch.randn(C, C, 3, 1, 1, generator=g) / math.sqrt(3 * C)).to(dtype)
+    bt = torch.randn(C, generator=g)
+    a = xt[0].permute(1, 2, 3, 0).reshape(-1, C).contiguous()
+    wtp = wt[:, :, :, 0, 0].permute(0, 2, 1).reshape(C, 3 * C).contiguous()
+    ad, wtd, btd = dev(ctx, a), dev(ctx, wtp), dev(ctx, bt)
+    ref = F.conv3d(xt.float(), wt.float(), bt, padding=(1, 0, 0))[0].permute(1, 2, 3, 0).reshape(-1, C) + a.float()
+    whole = ctx.gemm(ad, wtd, bias=btd, res=ad, mode=L.A_TCONV3, temporal=(Fr, 196, C), force_tile=1)
+    split = ctx.gemm(ad, wtd, bias=btd, res=ad, mode=L.A_TCONV3, temporal=(Fr, 196, C), force_tile=1008)
+    assert torch.equal(whole, split)
+    assert_close(split, ref, dtype, what="tconv tail split")
+    assert ctx.lib.gemm_split_count(ctx.h) == n0 + 1 + 4 + 3        # every automatic launch above was split
 
 
 @pytest.mark.parametrize("M,N,K", [(515, 512, 256), (300, 264, 64), (257, 256, 448), (130, 1280, 128)])
