@@ -70,6 +70,35 @@ STAR_DEV float gelu_erf(float x) {
   return fmaxf(x, 0.f) - ax * fast_exp2(p);
 }
 
+// the same on a PAIR of values: the degree-7 polynomial as seven v_pk_fma_f32 (packed fp32 is full rate on CDNA3/4: half the
+// instructions of two scalar chains; each element sees the same fma sequence as in gelu_erf -- bit-identical).  The GEGLU epilogues
+// are VALU-bound (the A-stationary kernel's exceeds what 80 MFMAs shadow; the persistent tile's runs with the matrix pipe idle).
+using f32x2 = vec<float, 2>;
+STAR_DEV f32x2 gelu_erf2(f32x2 x) {
+#ifdef STAR_HOSTEMU
+  f32x2 r; r[0] = gelu_erf(x[0]); r[1] = gelu_erf(x[1]);
+  return r;
+#else
+  f32x2 ax, z;
+  ax[0] = fabsf(x[0]); ax[1] = fabsf(x[1]);
+  z[0] = fminf(ax[0] * 0.70710678118654752440f, 4.5f); z[1] = fminf(ax[1] * 0.70710678118654752440f, 4.5f);
+  f32x2 p = {-2.045475840e-05f, -2.045475840e-05f};
+  const float c[7] = {4.882977128e-04f, -5.237886925e-03f, 3.395745580e-02f, -1.525140382e-01f, -9.170034400e-01f, -1.628095626e+00f, -9.999960965e-01f};
+#pragma unroll
+  for (int i = 0; i < 7; ++i) { const f32x2 cc = {c[i], c[i]}; p = __builtin_elementwise_fma(p, z, cc); }
+  f32x2 r;
+  r[0] = fmaxf(x[0], 0.f) - ax[0] * fast_exp2(p[0]);
+  r[1] = fmaxf(x[1], 0.f) - ax[1] * fast_exp2(p[1]);
+  return r;
+#endif
+}
+STAR_DEV f32x4 gelu_erf4(f32x4 x) {
+  f32x2 a = {x[0], x[1]}, b = {x[2], x[3]};
+  a = gelu_erf2(a); b = gelu_erf2(b);
+  f32x4 r = {a[0], a[1], b[0], b[1]};
+  return r;
+}
+
 // tanh-form GELU (sat.mpu.utils.gelu_impl: 0.5 x (1 + tanh(0.79788456 x (1 + 0.044715 x^2)))) = x sigmoid(2 u)
 STAR_DEV float gelu_tanh(float x) {
   const float u = 0.7978845608028654f * x * (1.0f + 0.044715f * x * x);
@@ -702,8 +731,7 @@ gemm_kernel(const GemmParams p) {
               for (int e = 0; e < 4; ++e) gt[e] = ra[i] * gt[e] + (rb[i] * cs[e] + cb[e]);
             } else
             gt += *reinterpret_cast<const f32x4*>(bias_lds + nl + 32);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = v[e] * gelu_erf(gt[e]);
+            v = v * gelu_erf4(gt);
             ncol = (j >> 1) * 32 + 8 * g + 4 * fhalf;
           }
           if constexpr (GELUTF) {

@@ -114,11 +114,10 @@ gemm_astat_kernel(const GemmParams p) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = ra[rb] * STAR_ACC(P)[rb][cb][g * 4 + e] + (rbv[rb] * ecs[U & 1][e] + ecb[U & 1][e]);
     if constexpr (GEGLU != 0) {
+      f32x4 gt;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float gt = ra[rb] * STAR_ACC(P)[rb][1][g * 4 + e] + (rbv[rb] * egs[U & 1][e] + egb[U & 1][e]);
-        v[e] = v[e] * gelu_erf(gt);
-      }
+      for (int e = 0; e < 4; ++e) gt[e] = ra[rb] * STAR_ACC(P)[rb][1][g * 4 + e] + (rbv[rb] * egs[U & 1][e] + egb[U & 1][e]);
+      v = v * gelu_erf4(gt);
     }
     vec<T, 4> o;
 #pragma unroll

@@ -78,7 +78,9 @@ bool gemm_persist_covers(const GemmArgs& a);
 
 #ifdef STAR_BENCH_VARIANTS
 static bool no_sched_env() { return std::getenv("STAR_NO_SCHED") != nullptr; }
+static bool no_persist_env() { return std::getenv("STAR_NO_PERSIST") != nullptr; }
 #else
+static bool no_persist_env() { static const bool v = std::getenv("STAR_NO_PERSIST") != nullptr; return v; }   // read once (A/B switch)
 static bool no_sched_env() { static const bool v = std::getenv("STAR_NO_SCHED") != nullptr; return v; }   // read once (A/B switch)
 #endif
 
@@ -99,7 +101,20 @@ static int launch_gemm(Ctx* ctx, const GemmArgs& a) {
     const bool sched_ok = (a.mode == A_CONV3X3 || a.mode == A_TCONV3) && a.N % 256 == 0 && a.K >= 2560 &&
                           !(a.epi & (EPI_OUT_F32 | EPI_ROWAFF | EPI_GELU_TANH | EPI_GEGLU)) &&
                           (int64_t)((a.M + 255) / 256) * (a.N / 256) >= 512 && !no_sched_env();
-    if (sched_ok) tile = 17;
+    // plain-A layers with K >= 512 whose width is a whole number of 256-column tiles and that fill the chip at least twice: the
+    // persistent one-wave-per-SIMD tile (gemm_p.h), 5-9 % ahead of the 8-wave tiles there (q | k | v, out-projections and FF-out of
+    // level 2, the GEGLU projections of levels 1-2, the DiT dense layers: profiles/r04_gemm_ab.txt); narrower or ragged widths lose
+    // to the 256 x 320 tile (N = 640 would waste a sixth of three 256-column tiles)
+    // ... and whose tiles fill the resident workgroups' rounds to >= 88 % (the persistent walk is static: 1080 tiles on 256 CUs are 5
+    // rounds for some workgroups; there the 256 x 320 tile + tail split measured ahead, profiles/r04_gemm_ab_v3_auto.txt)
+    bool persist_ok = gemm_persist_covers(a) && a.K >= 512 && a.N % 256 == 0 && a.N >= 1024 && !no_persist_env();
+    if (persist_ok) {
+      const int cus = a.assume_cus > 0 ? a.assume_cus : (ctx->num_cus > 0 ? ctx->num_cus : 256);
+      const int64_t nt = (int64_t)((a.M + 255) / 256) * (a.N / 256), rounds = (nt + cus - 1) / cus;
+      persist_ok = nt >= 2 * (int64_t)cus && (double)nt >= 0.88 * (double)(rounds * cus);
+    }
+    if (persist_ok) tile = 18;
+    else if (sched_ok) tile = 17;
     else if (a.M <= 4096 && a.N <= 1024) tile = 3;                     // small problems: more, smaller tiles
     else if (!geglu && a.N % 320 == 0) tile = 2;                        // 320 / 640 / 960 / 1280 / 1920-wide layers
     // (rounds 1-2 sent the short-K GEGLU layers to tile 9, two 4-wave workgroups per CU hiding each other's GELU epilogue;
@@ -113,7 +128,7 @@ static int launch_gemm(Ctx* ctx, const GemmArgs& a) {
   // their time with three quarters of the chip idle.  When the last round is poorly filled, the launch covers only the tile rows of
   // the FULL rounds and the remaining rows go to a second launch of 128 x 128 tiles (tile 3: two workgroups per CU, every mode and
   // epilogue flavour, same k order per output -- bit-identical).  Decided by a cost model in units of one big tile's time.
-  if (!a.force_tile && a.m_off == 0 && a.m_end == 0 && (tile == 1 || tile == 2 || tile == 17 || tile == 18)) {
+  if (!a.force_tile && a.m_off == 0 && a.m_end == 0 && (tile == 1 || tile == 2 || tile == 17)) {   // (the persistent tile 18 is only chosen where its rounds are full)
     const int cus = a.assume_cus > 0 ? a.assume_cus : (ctx->num_cus > 0 ? ctx->num_cus : 256);
     const int bm = 256, bn = tile == 2 ? 320 : 256;
     const long long tm = (a.M + bm - 1) / bm, tn = (a.N + bn - 1) / bn, nt = tm * tn;

@@ -4,10 +4,11 @@
 
 namespace star {
 
-// what the kernel can compute: plain A, 16-bit output, bias / residual / folded-LayerNorm epilogues
+// what the kernel can compute: plain A, 16-bit output, bias / residual / GEGLU / folded-LayerNorm epilogues
 bool gemm_persist_covers(const GemmArgs& a) {
   if (a.mode != A_PLAIN || a.K % 64 || a.K < 64 || a.N % 8 || a.lda % 8 || a.ldc % 8) return false;
-  if (a.epi & (EPI_OUT_F32 | EPI_GEGLU | EPI_GELU_TANH)) return false;
+  if (a.epi & (EPI_OUT_F32 | EPI_GELU_TANH)) return false;
+  if ((a.epi & EPI_GEGLU) && ((a.epi & EPI_RES) || a.N % 64)) return false;
   if ((a.epi & EPI_RES) && a.ldr % 8) return false;
   if (a.epi & EPI_ROWAFF) return !(a.epi & EPI_RES) && (a.epi & EPI_BIAS) && a.rowab && a.colsum && a.bias;
   return true;
@@ -30,14 +31,16 @@ static int launch_persist_t(Ctx* ctx, const GemmArgs& a) {
   if (G >= 8) G &= ~7;
   constexpr size_t smem = 2 * (size_t)(256 + 256) * 128 + 4 * (size_t)4096 + 2 * (size_t)2048;
   const dim3 grid((unsigned)G), block(256);
-  if (a.epi & EPI_ROWAFF) STAR_LAUNCH((gemm_persist_kernel<T, 8>), grid, block, smem, ctx->stream, p);
+  if ((a.epi & EPI_ROWAFF) && (a.epi & EPI_GEGLU)) STAR_LAUNCH((gemm_persist_kernel<T, 10>), grid, block, smem, ctx->stream, p);
+  else if (a.epi & EPI_GEGLU) STAR_LAUNCH((gemm_persist_kernel<T, 2>), grid, block, smem, ctx->stream, p);
+  else if (a.epi & EPI_ROWAFF) STAR_LAUNCH((gemm_persist_kernel<T, 8>), grid, block, smem, ctx->stream, p);
   else if (a.epi & EPI_RES) STAR_LAUNCH((gemm_persist_kernel<T, 1>), grid, block, smem, ctx->stream, p);
   else STAR_LAUNCH((gemm_persist_kernel<T, 0>), grid, block, smem, ctx->stream, p);
   return 0;
 }
 
 int launch_gemm_persist(Ctx* ctx, const GemmArgs& a) {
-  if (!gemm_persist_covers(a)) return ctx->fail("gemm (persistent tile 18): plain-A layers with the bias / residual / folded-LayerNorm 16-bit epilogues only");
+  if (!gemm_persist_covers(a)) return ctx->fail("gemm (persistent tile 18): plain-A layers with the bias / residual / GEGLU / folded-LayerNorm 16-bit epilogues only");
   if ((size_t)256 * a.lda * 2 >= ((size_t)1 << 32) || (size_t)256 * a.ldc * 2 >= ((size_t)1 << 32) || (size_t)256 * a.K * 2 >= ((size_t)1 << 32))
     return ctx->fail("gemm (persistent tile 18): rows too long for 32-bit buffer ranges");
   if (ctx->dtype == DT_F16) return launch_persist_t<f16>(ctx, a);

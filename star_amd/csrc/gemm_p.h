@@ -23,14 +23,15 @@
 
 namespace star {
 
-template <class T, int EPIF>   // EPIF: bit 0 residual add, bit 3 row-affine (folded LayerNorm); 16-bit output
+template <class T, int EPIF>   // EPIF: bit 0 residual add, bit 1 GEGLU (weight rows in 32-row (value, gate) blocks), bit 3 row-affine (folded LayerNorm); 16-bit output
 STAR_GLOBAL void STAR_LAUNCH_BOUNDS(256, 1)
 gemm_persist_kernel(const GemmParams p) {
   constexpr int BM = 256, BN = 256, NT = 256, NP = 8;      // NP: 16-byte pieces per thread and operand and K tile
   constexpr int A_STAGE = BM * 128, W_STAGE = BN * 128;
   constexpr int STG_OFF = 2 * A_STAGE + 2 * W_STAGE, STG = 32 * 128;
   constexpr int BIAS_OFF = STG_OFF + 4 * STG;              // 2 parities x [bias 256 | colsum 256] fp32
-  constexpr bool RESF = (EPIF & 1) != 0, ROWAFF = (EPIF & 8) != 0;
+  constexpr bool RESF = (EPIF & 1) != 0, GEGLUF = (EPIF & 2) != 0, ROWAFF = (EPIF & 8) != 0;
+  static_assert(!(RESF && GEGLUF), "GEGLU layers have no residual");
   char* smem = dyn_smem();
   const int tid = (int)threadIdx.x, lane = tid & 63;
   const int wv = wave_uniform(tid >> 6);
@@ -174,15 +175,19 @@ gemm_persist_kernel(const GemmParams p) {
   };
   // One K tile (stage buf): phase 0 carries the W pieces of the NEXT K tile of the stream (into the other stage), phase 3 the A
   // pieces of the next-but-one (into this stage, read out behind the barrier of phase 2) -- across output tiles alike.
-  auto ktile = [&](int buf, auto fresh, int n0_bias, int par_bias) STAR_ALWAYS_INLINE {
-    constexpr bool FRESH = decltype(fresh)::value;
+  // STEADY: both streams are known to be live (every K tile but the last two of the workgroup's whole stream): no branch between
+  // the MFMAs.  (The first build tested the streams' flags around each of the 16 copies: 16 s_cbranch + v_cndmask / v_cmp per K
+  // tile, 8192^3 4 % behind tile 17 instead of ahead.)
+  auto ktile = [&](int buf, auto fresh, auto steady, int n0_bias, int par_bias) STAR_ALWAYS_INLINE {
+    constexpr bool FRESH = decltype(fresh)::value, STEADY = decltype(steady)::value;
+    const bool wl = STEADY || sw_live, al = STEADY || sa_live;
     phase(B0{}, fresh, [&](auto q) STAR_ALWAYS_INLINE {
       constexpr int Q = decltype(q)::value;
       rd(B1{}, q, B1{});
-      if constexpr ((Q & 1) == 1) { if (sw_live) w_piece(buf ^ 1, std::integral_constant<int, (Q >> 1)>{}); }
+      if constexpr ((Q & 1) == 1) { if (wl) w_piece(buf ^ 1, std::integral_constant<int, (Q >> 1)>{}); }
       if constexpr (FRESH && Q == 14) bias_pieces(n0_bias, par_bias);
     });
-    if (sw_live) w_advance();
+    if (wl) w_advance();
     phase(B1{}, std::false_type{}, [&](auto q) STAR_ALWAYS_INLINE { rd(std::integral_constant<int, 2>{}, q, B0{}); });
     phase(B0{}, std::false_type{}, [&](auto q) STAR_ALWAYS_INLINE {
       constexpr int Q = decltype(q)::value;
@@ -194,9 +199,9 @@ gemm_persist_kernel(const GemmParams p) {
     phase(B1{}, std::false_type{}, [&](auto q) STAR_ALWAYS_INLINE {
       constexpr int Q = decltype(q)::value;
       rd(B0{}, q, B0{});
-      if constexpr ((Q & 1) == 1) { if (sa_live) a_piece(buf, std::integral_constant<int, (Q >> 1)>{}); }
+      if constexpr ((Q & 1) == 1) { if (al) a_piece(buf, std::integral_constant<int, (Q >> 1)>{}); }
     });
-    if (sa_live) a_advance();
+    if (al) a_advance();
   };
 
   // ---- epilogue (wave-private; every lane-derived address is re-derived per tile from an opaquely re-read thread id: hipcc
@@ -223,9 +228,11 @@ gemm_persist_kernel(const GemmParams p) {
     }
     // byte offset of this lane's 16-byte chunk in row (wm * 128 + (le >> 3)) of the tile, for the two 64-column halves; a chunk past
     // column N gets an offset outside every descriptor range (dropped); rows past M fall outside the descriptor by themselves
-    const int colb = n0 + wn * 128 + (le & 7) * 8;
+    // (GEGLU: a wave's 128 columns give 64 outputs = ONE 128-byte line per row, columns (n0 + 128 wn) / 2 ...)
+    const int n_out = GEGLUF ? p.N / 2 : p.N;
+    const int colb = (GEGLUF ? (n0 + wn * 128) / 2 : n0 + wn * 128) + (le & 7) * 8;
     uint32_t voff = (uint32_t)((wm * 128 + (le >> 3)) * p.ldc + colb) * 2u;
-    const uint32_t dead0 = colb < p.N ? 0u : GLDS_BUF_OOB, dead1 = colb + 64 < p.N ? 0u : GLDS_BUF_OOB;
+    const uint32_t dead0 = colb < n_out ? 0u : GLDS_BUF_OOB, dead1 = colb + 64 < n_out ? 0u : GLDS_BUF_OOB;
     const uint32_t step = (uint32_t)p.ldc * 16u;                               // 8 rows down
     // the residual through a descriptor of its own (rows past M / columns past N read as zeros; those results are never stored)
     BufRsrc rrs = crs;
@@ -244,6 +251,31 @@ gemm_persist_kernel(const GemmParams p) {
         if constexpr (jh == 1) roff += 4 * rstep;
       }
       // registers -> the wave's staging block: row fr, 16-byte chunk c = (column within the 64) / 8 at c ^ (fr & 7), half fh
+      if constexpr (GEGLUF) {
+        // value block 2 jh, gate block 2 jh + 1 -> 32 outputs per row: chunks 4 jh .. 4 jh + 3; the line is complete after jh = 1
+        STAR_AGPR_PIN(acc[i][2 * jh]);
+        STAR_AGPR_PIN(acc[i][2 * jh + 1]);
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int nl = 2 * jh * 32 + 8 * g4;
+          f32x4 v, gt;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[e] = acc[i][2 * jh][g4 * 4 + e]; gt[e] = acc[i][2 * jh + 1][g4 * 4 + e]; }
+          const f32x4 cb = *reinterpret_cast<const f32x4*>(bl + nl), gb = *reinterpret_cast<const f32x4*>(bl + nl + 32);
+          if constexpr (ROWAFF) {
+            const f32x4 cs = *reinterpret_cast<const f32x4*>(bl + 256 + nl), gs = *reinterpret_cast<const f32x4*>(bl + 256 + nl + 32);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = ra[i] * v[e] + (rb[i] * cs[e] + cb[e]); gt[e] = ra[i] * gt[e] + (rb[i] * gs[e] + gb[e]); }
+          } else {
+            v += cb; gt += gb;
+          }
+          v = v * gelu_erf4(gt);
+          vec<T, 4> o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = from_f32<T>(v[e]);
+          *reinterpret_cast<vec<T, 4>*>(const_cast<char*>(stw) + (((jh * 4 + g4) ^ sw7) << 4)) = o;
+        }
+      } else {
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {
         // the block's accumulators are in the accumulator half of the register file UNTIL HERE: without the pin the register allocator
@@ -269,6 +301,8 @@ gemm_persist_kernel(const GemmParams p) {
           *reinterpret_cast<vec<T, 4>*>(const_cast<char*>(stw) + (((jj * 4 + g4) ^ sw7) << 4)) = o;
         }
       }
+      }
+      if constexpr (!GEGLUF || jh == 1) {
       wave_lds_order();
       // LDS -> global: 4 instructions of 8 whole 128-byte lines each (+ residual, already in registers)
 #pragma unroll
@@ -278,10 +312,11 @@ gemm_persist_kernel(const GemmParams p) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) ov[e] = from_f32<T>(to_f32<T>(ov[e]) + to_f32<T>(rv[u][e]));
         }
-        buf_store16(crs, (voff + (uint32_t)(jh * 128)) | (jh ? dead1 : dead0), __builtin_bit_cast(u32x4, ov));
+        buf_store16(crs, (voff + (uint32_t)(GEGLUF ? 0 : jh * 128)) | ((!GEGLUF && jh) ? dead1 : dead0), __builtin_bit_cast(u32x4, ov));
         voff += step;                                   // next 8 rows
       }
-      if constexpr (jh == 0) voff -= 4 * step;           // back to the unit's first rows for the second half
+      if constexpr (!GEGLUF && jh == 0) voff -= 4 * step;   // back to the unit's first rows for the second half
+      }
       wave_lds_order();   // the block is read out before the next unit writes it (DS operations of a wave execute in order)
       STAR_SCHED_FENCE();  // units stay apart: hoisting the next units' accumulator reads costs ~20 registers of scratch
     });
@@ -307,9 +342,14 @@ gemm_persist_kernel(const GemmParams p) {
   for (int i = 0; i < ntm; ++i) {
     int m0, n0;
     tile_origin(i, m0, n0);
-    ktile(g & 1, std::true_type{}, n0, i & 1);
+    // the last two K tiles of the workgroup's stream have nothing (or only W) left to stage: guarded form; all others: steady form
+    const int nks = (i == ntm - 1) ? (nk > 2 ? nk - 2 : 0) : nk;
+    if (nks > 0) ktile(g & 1, std::true_type{}, std::true_type{}, n0, i & 1);
+    else ktile(g & 1, std::true_type{}, std::false_type{}, n0, i & 1);
     ++g;
-    for (int kt = 1; kt < nk; ++kt, ++g) ktile(g & 1, std::false_type{}, 0, 0);
+    int kt = 1;
+    for (; kt < nks; ++kt, ++g) ktile(g & 1, std::false_type{}, std::true_type{}, 0, 0);
+    for (; kt < nk; ++kt, ++g) ktile(g & 1, std::false_type{}, std::false_type{}, 0, 0);
     epilogue(m0, n0, i & 1);
   }
 }

@@ -16,8 +16,39 @@ STAR_DEV float sigmoid_f(float x) { return fast_rcp(1.0f + fast_exp2(-1.44269504
 // reference: nn.GroupNorm(32, C) on (b f) c h w  [stats per frame]  unet_v2v.py:610,635,268
 //            nn.GroupNorm(32, C) on  b c f h w   [stats over the whole chunk] unet_v2v.py:1210-1219,1002
 struct GnStatsParams {
-  const void* x; int ld; int C; int rows_per_stat; int slab; double* partial;  // partial[nstat][nslab][32][2]
+  const void* x; int ld; int C; int rows_per_stat; int slab; double* partial;  // partial[nstat][32][nslab][2]: a group's slab partials are contiguous
+  // finalize folded into this kernel (2 launches per GroupNorm instead of 3): the LAST block of a stat to finish -- elected by an
+  // arrival counter, the only atomic on the path; it decides who reduces, never in which order -- turns the partials of its stat
+  // into the per-channel affine pairs with gn_finalize's exact arithmetic.  counter == nullptr: the separate finalize kernel runs.
+  int* counter; const float* gamma; const float* beta; float* ab; double count; float eps;
 };
+// partial sums of one (stat, group) -> the affine pairs of the group's channels: one wavefront, lanes stride over the slabs in
+// order, then a fixed shuffle tree (shared by the folded and the separate finalize: bit-identical results)
+STAR_DEV void gn_finalize_group(const double* partial, int nslab, int stat, int g, int C, double count, float eps, const float* gamma,
+                                const float* beta, float* ab, int lane) {
+  double a = 0.0, b = 0.0;
+  const double* q0 = partial + ((size_t)stat * 32 + g) * (size_t)nslab * 2;
+  for (int sl = lane; sl < nslab; sl += 64) {
+    a += q0[2 * sl];
+    b += q0[2 * sl + 1];
+  }
+  // fixed-order tree over the 64 lanes (two floats carry one double: hi/lo split keeps it exact enough and deterministic)
+  for (int m = 32; m >= 1; m >>= 1) {
+    const float ah = (float)a, al = (float)(a - (double)ah), bh = (float)b, bl = (float)(b - (double)bh);
+    a += (double)shfl_xor(ah, m) + (double)shfl_xor(al, m);
+    b += (double)shfl_xor(bh, m) + (double)shfl_xor(bl, m);
+  }
+  const double mean = a / count;
+  double var = b / count - mean * mean;
+  if (var < 0) var = 0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const int cg = C >> 5;
+  for (int c = g * cg + lane; c < (g + 1) * cg; c += 64) {
+    const float sc = gamma[c] * rstd;
+    ab[2 * ((size_t)stat * C + c)] = sc;
+    ab[2 * ((size_t)stat * C + c) + 1] = beta[c] - (float)mean * sc;
+  }
+}
 // Deterministic by construction (fixed reduction order, no atomics): every launch gives bit-identical statistics, hence a
 // bit-reproducible forward.  Per block: threads own a fixed 8-channel chunk and stride over the slab's rows; the per-thread
 // sums go through LDS and are reduced in index order by one thread per group.
@@ -71,10 +102,32 @@ STAR_GLOBAL void gn_stats_kernel(const GnStatsParams p) {
         b += (double)q[8 + e];
       }
     }
-    double* out = p.partial + (((size_t)stat * gridDim.x + slab_id) * 32 + t) * 2;
+    double* out = p.partial + (((size_t)stat * 32 + t) * gridDim.x + slab_id) * 2;
     out[0] = a;
     out[1] = b;
   }
+  if (p.counter == nullptr) return;
+  // ---- arrival: the last block of this stat finalizes it (every block's partials are globally visible before it arrives)
+  int* flag = reinterpret_cast<int*>(ts);   // LDS word 0 is free again behind the barrier below
+  block_sync();
+  if (t == 0) {
+#ifdef STAR_HOSTEMU
+    const int old = p.counter[stat]++;
+#else
+    __threadfence();
+    const int old = atomicAdd(p.counter + stat, 1);
+#endif
+    *flag = (old == (int)gridDim.x - 1) ? 1 : 0;
+  }
+  block_sync();
+  if (*flag == 0) return;
+#ifndef STAR_HOSTEMU
+  __threadfence();
+#endif
+  if (t == 0) p.counter[stat] = 0;   // ready for the next GroupNorm on this stream
+  const int nw = (int)blockDim.x >> 6, wv = t >> 6, lane = t & 63;
+  if (wv >= nw) return;              // (a trailing partial wavefront does not take part: the shuffles need all 64 lanes)
+  for (int g = wv; g < 32; g += nw) gn_finalize_group(p.partial, (int)gridDim.x, stat, g, p.C, p.count, p.eps, p.gamma, p.beta, p.ab, lane);
 }
 
 // partial sums -> per-(stat, channel) affine (a, b): y = x*a + b.  One wavefront per (stat, group): lanes stride over the
@@ -87,29 +140,7 @@ STAR_GLOBAL void gn_finalize_kernel(const GnFinalizeParams p) {
   const int lane = threadIdx.x & 63;
   const int wg = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);   // (stat, group) index
   if (wg >= p.nstat * 32) return;
-  const int stat = wg >> 5, g = wg & 31;
-  double a = 0.0, b = 0.0;
-  for (int sl = lane; sl < p.nslab; sl += 64) {
-    const double* q = p.partial + (((size_t)stat * p.nslab + sl) * 32 + g) * 2;
-    a += q[0];
-    b += q[1];
-  }
-  // fixed-order tree over the 64 lanes (two floats carry one double: hi/lo split keeps it exact enough and deterministic)
-  for (int m = 32; m >= 1; m >>= 1) {
-    const float ah = (float)a, al = (float)(a - (double)ah), bh = (float)b, bl = (float)(b - (double)bh);
-    a += (double)shfl_xor(ah, m) + (double)shfl_xor(al, m);
-    b += (double)shfl_xor(bh, m) + (double)shfl_xor(bl, m);
-  }
-  const double mean = a / p.count;
-  double var = b / p.count - mean * mean;
-  if (var < 0) var = 0;
-  const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
-  const int cg = p.C >> 5;
-  for (int c = g * cg + lane; c < (g + 1) * cg; c += 64) {
-    const float sc = p.gamma[c] * rstd;
-    p.ab[2 * ((size_t)stat * p.C + c)] = sc;
-    p.ab[2 * ((size_t)stat * p.C + c) + 1] = p.beta[c] - (float)mean * sc;
-  }
+  gn_finalize_group(p.partial, p.nslab, wg >> 5, wg & 31, p.C, p.count, p.eps, p.gamma, p.beta, p.ab, lane);
 }
 
 struct GnApplyParams {

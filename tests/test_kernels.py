@@ -184,14 +184,14 @@ def test_temporal_conv(ctx, dtype, Fr, H, Wd, C):
     assert_close(out, ref, dtype, what="tconv")
 
 
-@pytest.mark.parametrize("M,N,K,wgs", [(515, 512, 256, 0), (300, 264, 64, 0), (700, 600, 192, 2), (257, 1288, 128, 3), (1030, 256, 448, 1), (64, 8, 64, 0),
+@pytest.mark.parametrize("M,N,K,wgs", [(515, 512, 256, 0), (300, 264, 64, 0), (700, 600, 192, 2), (257, 1288, 128, 3), (1030, 256, 448, 1), (64, 8, 64, 0), (700, 576, 128, 2),
                                         (2100, 1920, 640, 8)])
 def test_gemm_persistent_tile(ctx, dtype, M, N, K, wgs):
     """tile 18 (gemm_p.h): resident workgroups walk their output tiles, the K tiles of all of them form one LDS-DMA stream (operands
     through hand-built buffer descriptors: ragged rows / columns read as zeros), zero-C MFMAs open a tile, wave-private epilogue.
     Bias / residual / folded-LayerNorm flavours against fp32 and BIT FOR BIT against the 8-wave tile (same k order per output);
     `wgs` resident workgroups (force_tile 2000 + n) so that a workgroup streams across several output tiles, with odd and single K
-    tile counts and ragged edges; GEGLU / fp32 output are refused."""
+    tile counts and ragged edges; fp32 output is refused."""
     if M * N * K > 6e8 and ctx.lib.is_hostemu:
         pytest.skip("hardware-only size")
     g = torch.Generator().manual_seed(M + 3 * N + K)
@@ -211,9 +211,12 @@ def test_gemm_persistent_tile(ctx, dtype, M, N, K, wgs):
         assert_close(out, ref, dtype, scale=6.0, what=f"gemm tile 18 {list(kw)}")
     with pytest.raises(L.StarError):
         ctx.gemm(Ad, Wd_, bias=bd, out_f32=True, force_tile=18)
-    if N % 64 == 0:
+    if N % 64 == 0:   # GEGLU (32-row value / gate blocks), plain and with the folded LayerNorm: bit for bit against the 8-wave tile
+        for kw in (dict(bias=bd, geglu=True), dict(bias=bd, geglu=True, rowab=dev(ctx, rowab), colsum=dev(ctx, colsum))):
+            out = ctx.gemm(Ad, Wd_, force_tile=ft, **kw)
+            assert out.shape == (M, N // 2) and torch.equal(out, ctx.gemm(Ad, Wd_, force_tile=1, **kw)), kw.keys()
         with pytest.raises(L.StarError):
-            ctx.gemm(Ad, Wd_, bias=bd, geglu=True, force_tile=18)
+            ctx.gemm(Ad, Wd_, bias=bd, res=Rd, geglu=True, force_tile=18)
 
 
 def test_gemm_tail_split_is_bit_identical(ctx, dtype):

@@ -37,16 +37,20 @@ if what == "plain":
     # (M, N, K, flavour): the plain-A layers of levels 1-2 with K >= 640 (profiles/r03_forward_detail_f16_v1.txt)
     shapes = [(214272, 1920, 640, "rowaff"), (55296, 3840, 1280, "rowaff"), (214272, 640, 640, "res"), (55296, 1280, 1280, "res"),
               (214272, 640, 2560, "res"), (55296, 1280, 5120, "res"), (55296, 1280, 1280, "bias"), (214272, 640, 640, "bias"),
-              (843264, 320, 1280, "res"), (8192, 8192, 8192, "none"), (9676, 9216, 3072, "bias"), (9676, 3072, 12288, "bias")]
+              (843264, 320, 1280, "res"), (8192, 8192, 8192, "none"), (9676, 9216, 3072, "bias"), (9676, 3072, 12288, "bias"),
+              (214272, 5120, 640, "geglu"), (55296, 10240, 1280, "geglu"), (843264, 4096, 512, "geglu"), (843264, 1536, 512, "rowaff")]
+    if len(sys.argv) > 2:
+        shapes = [sh for sh in shapes if sh[3] in sys.argv[2].split(",")]
     for (M, N, K, fl) in shapes:
         A = torch.randn(M, K, device="cuda", dtype=dt); W = torch.randn(N, K, device="cuda", dtype=dt) * 0.05
-        b = torch.randn(N, device="cuda"); R = torch.randn(M, N, device="cuda", dtype=dt)
+        b = torch.randn(N, device="cuda"); R = torch.randn(M, N, device="cuda", dtype=dt) if fl == "res" else None
         rowab = torch.rand(M, 2, device="cuda") + 0.5; colsum = W.float().sum(1).contiguous()
-        out = torch.empty(M, N, device="cuda", dtype=dt)
-        kw = {"none": {}, "bias": dict(bias=b), "res": dict(bias=b, res=R), "rowaff": dict(bias=b, rowab=rowab, colsum=colsum)}[fl]
+        out = torch.empty(M, N // 2 if fl == "geglu" else N, device="cuda", dtype=dt)
+        kw = {"none": {}, "bias": dict(bias=b), "res": dict(bias=b, res=R), "rowaff": dict(bias=b, rowab=rowab, colsum=colsum),
+              "geglu": dict(bias=b, rowab=rowab, colsum=colsum, geglu=True)}[fl]
         v = {}
-        for t in ([1, 2, 17, 18, 0] if N % 320 == 0 else [1, 17, 18, 0]):
-            if t == 17 and fl == "rowaff": continue
+        for t in ([1, 18, 0] if fl == "geglu" else [1, 2, 17, 18, 0] if N % 320 == 0 else [1, 17, 18, 0]):
+            if t == 17 and fl in ("rowaff", "geglu"): continue
             v[f"t{t}"] = (lambda t=t: ctx.gemm(A, W, out=out, force_tile=t, **kw))
         run(f"{M}x{N}x{K} {fl}", M, N, K, v, 2.0 * M * N * K)
         del A, W, R, out
