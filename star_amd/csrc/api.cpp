@@ -75,12 +75,6 @@ int star_ctx_create(int device_id, int dtype, star_ctx** out) {
   rt::stream_sync(nullptr);
   h->c.zero_page = z;
   h->c.num_cus = rt::device_cu_count(device_id);
-  void* gc = nullptr;
-  if (!rt::dev_malloc(&gc, Ctx::GN_COUNTERS * sizeof(int))) {   // without them GroupNorm keeps its separate finalize kernel
-    rt::memset_async(gc, 0, Ctx::GN_COUNTERS * sizeof(int), nullptr);
-    rt::stream_sync(nullptr);
-    h->c.gn_counter = (int*)gc;
-  }
   *out = h;
   return 0;
 }
@@ -94,7 +88,6 @@ void star_ctx_destroy(star_ctx* h) {
   text_release(&h->c);
   h->c.pool.release();
   if (h->c.zero_page) rt::dev_free(h->c.zero_page);
-  if (h->c.gn_counter) rt::dev_free(h->c.gn_counter);
   delete h;
 }
 

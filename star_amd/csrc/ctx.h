@@ -117,8 +117,6 @@ struct Ctx {
   std::string err;
   Pool pool;
   void* zero_page = nullptr;  // 256 B of zeros (conv padding source)
-  static constexpr int GN_COUNTERS = 1024;
-  int* gn_counter = nullptr;  // GN_COUNTERS zeroed ints: arrival counters of the GroupNorm statistics kernel (norm.h), reset by their last block
   std::unordered_map<std::string, HostTensor> host_tensors;  // staged by star_load_tensor
   std::shared_ptr<UNetModel> unet;   // shared_ptr: deleter bound where the type is complete
   std::shared_ptr<VaeModel> vae;

@@ -28,21 +28,16 @@ static int gn_t(Ctx* ctx, const void* x, int ldx, void* y, int ldy, const float*
   Buf ab(ctx, ab_out ? 0 : (size_t)nstat * C * 2 * sizeof(float));
   float* abp = ab_out ? ab_out : ab.as<float>();
   if (!partial.p || !abp) return ctx->fail("group_norm: out of device memory");
-  // finalize folded into the statistics kernel (its last block per stat, norm.h) unless switched off for an A/B or the stat count
-  // exceeds the context's arrival counters
-  // Measured (profiles/r04_gn_fold_ab.txt): with ONE stat (whole-chunk norms: 3294 slabs at level 0) the electing block reduces 32
-  // groups x all slabs on three or four wavefronts while the chip idles -- the family ran 2x slower; per-frame norms have one
-  // finalizing block per frame (32 at a time, 103 slabs each).  So: folded for >= 8 stats, the separate kernel otherwise.
-  static const bool no_fold = std::getenv("STAR_GN_NOFOLD") != nullptr;
-  int* counter = (!no_fold && ctx->gn_counter && nstat >= 8 && nstat <= Ctx::GN_COUNTERS && nthreads >= 64) ? ctx->gn_counter : nullptr;
+  // (Round 4 folded the finalize step into the statistics kernel -- its last block per stat, elected by an arrival counter, partials
+  // laid out [stat][group][slab] -- and measured it SLOWER: 2x for the family with every norm folded, +28 % with only the per-frame
+  // norms folded (profiles/r04_gn_fold_ab.txt): the agent-scope release every block needs before it arrives writes back / invalidates
+  // the XCD's L2, and a whole-chunk norm's single electing block reduces 3294 slabs alone.  Three launches it stays.)
   const double count = (double)rows_per_stat * (C / 32);
-  GnStatsParams sp{x, ldx, C, rows_per_stat, slab, partial.as<double>(), counter, gamma, beta, abp, count, eps};
+  GnStatsParams sp{x, ldx, C, rows_per_stat, slab, partial.as<double>()};
   dim3 grid((unsigned)nslab, (unsigned)nstat);
   STAR_LAUNCH((gn_stats_kernel<T>), grid, dim3(nthreads), (size_t)nthreads * 64, ctx->stream, sp);
-  if (!counter) {
-    GnFinalizeParams fp{partial.as<double>(), gamma, beta, abp, C, nstat, nslab, count, eps};
-    STAR_LAUNCH(gn_finalize_kernel, dim3((unsigned)((nstat * 32 + 3) / 4)), dim3(256), (size_t)0, ctx->stream, fp);
-  }
+  GnFinalizeParams fp{partial.as<double>(), gamma, beta, abp, C, nstat, nslab, count, eps};
+  STAR_LAUNCH(gn_finalize_kernel, dim3((unsigned)((nstat * 32 + 3) / 4)), dim3(256), (size_t)0, ctx->stream, fp);
   if (ab_out) return 0;
   GnApplyParams ap{x, y, abp, ldx, ldy, C, rows_per_stat, slab, silu ? 1 : 0};
   STAR_LAUNCH((gn_apply_kernel<T>), grid, dim3(nthreads), (size_t)0, ctx->stream, ap);

@@ -17,10 +17,6 @@ STAR_DEV float sigmoid_f(float x) { return fast_rcp(1.0f + fast_exp2(-1.44269504
 //            nn.GroupNorm(32, C) on  b c f h w   [stats over the whole chunk] unet_v2v.py:1210-1219,1002
 struct GnStatsParams {
   const void* x; int ld; int C; int rows_per_stat; int slab; double* partial;  // partial[nstat][32][nslab][2]: a group's slab partials are contiguous
-  // finalize folded into this kernel (2 launches per GroupNorm instead of 3): the LAST block of a stat to finish -- elected by an
-  // arrival counter, the only atomic on the path; it decides who reduces, never in which order -- turns the partials of its stat
-  // into the per-channel affine pairs with gn_finalize's exact arithmetic.  counter == nullptr: the separate finalize kernel runs.
-  int* counter; const float* gamma; const float* beta; float* ab; double count; float eps;
 };
 // partial sums of one (stat, group) -> the affine pairs of the group's channels: one wavefront, lanes stride over the slabs in
 // order, then a fixed shuffle tree (shared by the folded and the separate finalize: bit-identical results)
@@ -106,28 +102,6 @@ STAR_GLOBAL void gn_stats_kernel(const GnStatsParams p) {
     out[0] = a;
     out[1] = b;
   }
-  if (p.counter == nullptr) return;
-  // ---- arrival: the last block of this stat finalizes it (every block's partials are globally visible before it arrives)
-  int* flag = reinterpret_cast<int*>(ts);   // LDS word 0 is free again behind the barrier below
-  block_sync();
-  if (t == 0) {
-#ifdef STAR_HOSTEMU
-    const int old = p.counter[stat]++;
-#else
-    __threadfence();
-    const int old = atomicAdd(p.counter + stat, 1);
-#endif
-    *flag = (old == (int)gridDim.x - 1) ? 1 : 0;
-  }
-  block_sync();
-  if (*flag == 0) return;
-#ifndef STAR_HOSTEMU
-  __threadfence();
-#endif
-  if (t == 0) p.counter[stat] = 0;   // ready for the next GroupNorm on this stream
-  const int nw = (int)blockDim.x >> 6, wv = t >> 6, lane = t & 63;
-  if (wv >= nw) return;              // (a trailing partial wavefront does not take part: the shuffles need all 64 lanes)
-  for (int g = wv; g < 32; g += nw) gn_finalize_group(p.partial, (int)gridDim.x, stat, g, p.C, p.count, p.eps, p.gamma, p.beta, p.ab, lane);
 }
 
 // partial sums -> per-(stat, channel) affine (a, b): y = x*a + b.  One wavefront per (stat, group): lanes stride over the
