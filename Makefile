@@ -20,6 +20,7 @@ emu: tools/hostemu/libstar_emu.so
 build/hip/attn.o: HIPFLAGS += -fno-honor-nans -fno-slp-vectorize
 build/hip/attn7.o: HIPFLAGS += -fno-honor-nans -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form
 build/hip/gemm_as.o: HIPFLAGS += -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form
+build/hip/gemm_tq.o: HIPFLAGS += -fno-honor-nans -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form
 # precise header dependencies (-MMD): touching norm.h no longer recompiles the GEMM instantiation units (minutes each)
 build/hip/%.o: $(CSRC)/%.cpp
 	@mkdir -p build/hip
@@ -42,6 +43,7 @@ bench: tools/bench/libstar_hip_bench.so
 build/bench/attn.o: HIPFLAGS += -fno-honor-nans -fno-slp-vectorize
 build/bench/attn7.o: HIPFLAGS += -fno-honor-nans -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form
 build/bench/gemm_as.o: HIPFLAGS += -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form
+build/bench/gemm_tq.o: HIPFLAGS += -fno-honor-nans -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form
 build/bench/%.o: $(CSRC)/%.cpp
 	@mkdir -p build/bench
 	$(HIPCC) $(HIPFLAGS) -DSTAR_BENCH_VARIANTS=1 -MMD -MP -c $< -o $@

@@ -166,6 +166,9 @@ def main():
     ap.add_argument("--solver-mode", default=None, choices=["normal", "fast"])
     ap.add_argument("--max-chunk-len", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--breakdown", default="auto", choices=["auto", "on", "off"],
+                    help="per-family kernel times (HIP events around EVERY launch cost ~2 %% of a clip, so they are taken on an UNTIMED step: the last "
+                         "warm-up step (auto, when --warmup >= 1) or one extra step after the timed region (on)")
     ap.add_argument("--no-operand-sweep", action="store_true", help="skip the post-run power / clock sweep of the attention kernel (N = 1 only)")
     ap.add_argument("--small", action="store_true", help="reduced-width smoke configuration (NOT the metric)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl = RCCL over xGMI (default); gloo only for single-GPU plumbing tests")
@@ -256,11 +259,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
     uctx, vctx = model.generator.ctx, model.vae.ctx
+    prof_u_all = prof_v_all = None
+    for i in range(args.warmup):
+        last = i == args.warmup - 1 and args.breakdown != "off"
+        if last:                                   # the per-family breakdown: every launch bracketed, on an UNTIMED step
+            uctx.profile_begin(); vctx.profile_begin()
+        step()
+        if last:
+            prof_u_all, prof_v_all = uctx.profile_end(), vctx.profile_end()
     barrier()
-    uctx.profile_begin(); vctx.profile_begin()
+    # inside the timed region only the dominant kernel (spatial self-attention) is bracketed with HIP events: two event records per
+    # launch cost stream time, and a clip has ~340 000 launches (measured: 1.4 s of 61 s with all of them bracketed)
+    uctx.profile_begin(kinds=["attn_self"])
     power = PowerSampler(local_rank, 0.1).start() if rank == 0 else None
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -269,7 +280,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if power:
         power.stop()
-    prof_u, prof_v = uctx.profile_end(), vctx.profile_end()
+    prof_u = uctx.profile_end()
     if world > 1:
         import torch.distributed as dist
         tmax = torch.tensor([elapsed], device=dev if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
@@ -285,6 +296,10 @@ def main():
     d2h_ms = (time.perf_counter() - t1) * 1e3
     d2h_bytes = host_copy.numel() * 4
     del host_copy
+    if prof_u_all is None and args.breakdown == "on":   # one extra untimed step with every launch bracketed
+        uctx.profile_begin(); vctx.profile_begin()
+        step()
+        prof_u_all, prof_v_all = uctx.profile_end(), vctx.profile_end()
     sweep = None
     if rank == 0 and world == 1 and not args.small and not args.no_operand_sweep:
         del out, final
@@ -305,7 +320,7 @@ def main():
                 "achieved": (l0_flops / (a["max_flops_ms"] * 1e-3) / 1e12) if a["max_flops_ms"] else None,
                 "peak": PEAK_BF16_MFMA / 1e12, "traffic": traffic,
                 "traffic_source": f"profiles/{tname} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch)" if traffic else None,
-                "algorithmic_flops_per_launch": l0_flops, "avg_launch_ms": a["max_flops_ms"],
+                "algorithmic_flops_per_launch": l0_flops, "avg_launch_ms": a["max_flops_ms"],   # true mean over the L0 launches of the timed region
                 "all_self_attn_launches": {"launches": a["launches"], "ms": a["ms"], "TFLOP/s": a["flops"] / max(a["ms"], 1e-9) / 1e9}}
         roof["frac"] = roof["achieved"] / roof["peak"] if roof["achieved"] else None
         # power: sampled LIVE in this run (sysfs hwmon beside the kernels) -- over the whole timed region, and, after it, beside the
@@ -324,9 +339,9 @@ def main():
                                               "achieved": pk_["TFLOP/s"], "frac": pk_["frac_of_peak"], "socket_W": pk_["socket_W"], "sclk_MHz": pk_["sclk_MHz"]}
         roof["mfma_skeleton_ceiling_on_random_operands"] = {"TFLOP/s": 1568.0, "source": "static: profiles/r02_power_limit.txt (variant 16, N(0,1) f16), a round-2 measurement, not re-measured in this run",
                                                             "frac_of_it": roof["achieved"] / 1568.0 if roof["achieved"] else None}
-        breakdown = {k: {"ms": round(v["ms"], 1), "launches": v["launches"],
+        breakdown = None if prof_u_all is None else {k: {"ms": round(v["ms"], 1), "launches": v["launches"],
                          "TFLOP/s": round(v["flops"] / v["ms"] / 1e9, 1) if v["ms"] and v["flops"] else None,
-                         "GB/s": round(v["bytes"] / v["ms"] / 1e6, 1) if v["ms"] else None} for k, v in prof_u.items()}
+                         "GB/s": round(v["bytes"] / v["ms"] / 1e6, 1) if v["ms"] else None} for k, v in prof_u_all.items()}
         line = {
             "metric": "upscaled frames/sec (4x, 32f 240x426 chunk)" if args.config == "cfg2" and not custom else
                       f"upscaled frames/sec (4x, {args.frames}f {args.height}x{args.width}; BASELINE {args.config}{' modified' if custom else ''})",
@@ -342,7 +357,10 @@ def main():
                        "parallelism": (f"one video, solver-step chunks + VAE groups sharded over {world} ranks (RCCL all-gather of x0 cores / frames)"
                                        if shard_one_video else f"chunk-replicas x{world} + RCCL all-gather of frames")},
             "roofline": roof, "cpu_baseline": cpu_baseline,
-            "unet_kernel_ms": breakdown, "vae_kernel_ms": {k: round(v["ms"], 1) for k, v in prof_v.items()},
+            "unet_kernel_ms": breakdown, "vae_kernel_ms": None if prof_v_all is None else {k: round(v["ms"], 1) for k, v in prof_v_all.items()},
+            "kernel_ms_note": "per-family times of ONE UNTIMED step with HIP events around every launch (the last warm-up step, or --breakdown on); "
+                              "inside the timed region only the spatial self-attention launches are bracketed" if breakdown else
+                              "no breakdown in this run (--warmup 0 without --breakdown on)",
             "setup_s": {"weights": round(t_weights, 1), "load": round(t_load, 1)},
             "algorithmic_pflop_per_step": (2 * evals * cfg["chunks"] * cfg["fwd_tflop"] + args.frames * VAE_TFLOP_PER_FRAME * cfg["vae_scale"]) / 1e3
                                           if not args.small and not custom else None,

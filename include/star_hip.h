@@ -105,6 +105,18 @@ typedef struct star_tattn_desc {
 } star_tattn_desc;
 int star_temporal_attn_fwd(star_ctx* ctx, const star_tattn_desc* d);
 
+/* replaces: to_q / to_k / to_v (Linear, no bias) behind norm1 / norm2 AND the attention over the frame axis of the temporal branch in one
+ * kernel (unet_v2v.py:479-489, :151-195; level-0 width: C = 320, 5 heads, F <= 32 frames): x rows [F*HW][lda] -> O rows [F*HW][ldo].
+ * W: [960][320] = the LayerNorm-folded q | k | v weights (gamma o W) with their 64-row tiles ordered (q_h, k_h, v_h) per head;
+ * bias / colsum fp32 [960] in the same order; rowab from star_layer_norm_rowab.  Bit-identical to star_gemm (STAR_EPI_ROWAFF) followed
+ * by star_temporal_attn_fwd; q | k | v never reach HBM. */
+typedef struct star_tq_desc {
+  const void* A; const void* W; void* O; const float* bias; const float* colsum; const float* rowab;
+  int32_t lda, ldo, HW, F, C, heads;
+  float scale;
+} star_tq_desc;
+int star_temporal_qkv_attn(star_ctx* ctx, const star_tq_desc* d);
+
 /* replaces: nn.GroupNorm(32, C) [+ nn.SiLU] on 4-D (per-frame stats) and 5-D (whole-chunk stats) tensors
  * (unet_v2v.py:268,610,635,1002,1210-1219); rows_per_stat = H*W or F*H*W */
 int star_group_norm(star_ctx* ctx, const void* x, int32_t ldx, void* y, int32_t ldy, const float* gamma,
@@ -238,7 +250,10 @@ enum { STAR_PK_ATTN_SELF = 0, STAR_PK_ATTN_CROSS, STAR_PK_TATTN, STAR_PK_GEMM, S
        STAR_PK_LN, STAR_PK_MISC, STAR_PK_COUNT };
 typedef struct star_prof_entry { double ms; double flops; double bytes; double max_flops; double max_flops_ms; int64_t launches; } star_prof_entry;
 int star_profile_begin(star_ctx* ctx);
-/* synchronises, fills out[STAR_PK_COUNT], stops profiling */
+/* the same, bracketing only the kernel families whose bit (1 << STAR_PK_*) is set in kind_mask: two event records per launch cost stream
+ * time (measured 1.4 s of a 61 s clip with every launch bracketed), so bench.py times only the dominant kernel inside its timed region */
+int star_profile_begin_kinds(star_ctx* ctx, uint32_t kind_mask);
+/* synchronises, fills out[STAR_PK_COUNT] (max_flops_ms = mean duration of the family's largest launches), stops profiling */
 int star_profile_end(star_ctx* ctx, star_prof_entry* out);
 
 #ifdef __cplusplus

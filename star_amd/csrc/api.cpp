@@ -149,6 +149,14 @@ int star_temporal_attn_fwd(star_ctx* h, const star_tattn_desc* d) {
   a.F = d->F; a.HW = d->HW; a.heads = d->heads; a.scale = d->scale;
   return finish(h, op_temporal_attn(&h->c, a));
 }
+int star_temporal_qkv_attn(star_ctx* h, const star_tq_desc* d) {
+  if (h) rt::set_device(h->c.device);
+  if (!h || !d) return 1;
+  TqArgs a;
+  a.A = d->A; a.W = d->W; a.O = d->O; a.bias = d->bias; a.colsum = d->colsum; a.rowab = d->rowab;
+  a.lda = d->lda; a.ldo = d->ldo; a.HW = d->HW; a.F = d->F; a.C = d->C; a.heads = d->heads; a.scale = d->scale;
+  return finish(h, op_temporal_qkv_attn(&h->c, a));
+}
 int star_group_norm(star_ctx* h, const void* x, int32_t ldx, void* y, int32_t ldy, const float* gamma,
                     const float* beta, int32_t rows, int32_t C, int32_t rows_per_stat, float eps, int32_t silu) {
   if (h) rt::set_device(h->c.device);   // follow the context's device, not the caller's current one
@@ -317,8 +325,14 @@ int star_adain_color_fix(star_ctx* h, const float* target, const float* src, flo
 int star_profile_begin(star_ctx* h) {
   for (auto& r : h->c.prof) { rt::event_destroy(r.e0); rt::event_destroy(r.e1); }
   h->c.prof.clear();
+  h->c.prof_mask = ~0u;
   h->c.profiling = true;
   return 0;
+}
+int star_profile_begin_kinds(star_ctx* h, uint32_t kind_mask) {
+  const int rc = star_profile_begin(h);
+  if (!rc) h->c.prof_mask = kind_mask;
+  return rc;
 }
 int star_profile_end(star_ctx* h, star_prof_entry* out) {
   if (h) rt::set_device(h->c.device);   // follow the context's device, not the caller's current one
@@ -330,14 +344,17 @@ int star_profile_end(star_ctx* h, star_prof_entry* out) {
     }
   }
   for (int k = 0; k < PK_COUNT; ++k) out[k] = star_prof_entry{0, 0, 0, 0, 0, 0};
+  double big_ms[PK_COUNT] = {0};   // the family's largest launches (equal, maximal algorithmic work): sum and count -> a true mean
+  long long big_n[PK_COUNT] = {0};
   for (auto& r : h->c.prof) {
     const double ms = rt::event_elapsed_ms(r.e0, r.e1);
     star_prof_entry& e = out[r.kind];
     e.ms += ms; e.flops += r.flops; e.bytes += r.bytes; e.launches += 1;
-    if (r.flops > e.max_flops) { e.max_flops = r.flops; e.max_flops_ms = ms; }
-    else if (r.flops == e.max_flops && r.flops > 0) { e.max_flops_ms = 0.5 * (e.max_flops_ms + ms); }
+    if (r.flops > e.max_flops) { e.max_flops = r.flops; big_ms[r.kind] = ms; big_n[r.kind] = 1; }
+    else if (r.flops == e.max_flops && r.flops > 0) { big_ms[r.kind] += ms; big_n[r.kind] += 1; }
     rt::event_destroy(r.e0); rt::event_destroy(r.e1);
   }
+  for (int k = 0; k < PK_COUNT; ++k) if (big_n[k]) out[k].max_flops_ms = big_ms[k] / (double)big_n[k];
   h->c.prof.clear();
   h->c.profiling = false;
   return 0;

@@ -121,6 +121,9 @@ struct Ctx {
   std::shared_ptr<UNetModel> unet;   // shared_ptr: deleter bound where the type is complete
   std::shared_ptr<VaeModel> vae;
   bool profiling = false;
+  unsigned prof_mask = ~0u;   // kernel families (bit = ProfKind) that get HIP events while profiling: two event records per launch cost
+                              // ~2-4 us of stream time each -- 1.4 s of a 61 s clip with all ~340 000 launches bracketed (bench.py times only
+                              // the dominant kernel inside its timed region)
   std::vector<ProfRec> prof;
   bool unet_graph = false;   // star_unet_graph(): replay the UNet forward from a captured hipGraph (unet.cpp)
   int fail(const std::string& m) { err = m; return 1; }

@@ -197,6 +197,22 @@ struct Builder {
     }
     return fold_ln(r, {}, N, K, norm);
   }
+  // fused q | k | v with the LayerNorm folded in, rows re-ordered into 64-row tiles (q_h, k_h, v_h) per head (gemm_tq.h)
+  LinW fused_ln_heads(const std::vector<std::string>& names, const std::string& norm, int heads) {
+    std::vector<float> r; int K = 0, C = 0;
+    for (auto& nm : names) {
+      const HostTensor* w = get(nm + ".weight");
+      if (!w) return LinW{};
+      K = (int)(w->data.size() / (size_t)w->shape[0]); C = (int)w->shape[0];
+      r.insert(r.end(), w->data.begin(), w->data.end());
+    }
+    if (names.size() != 3 || C != heads * 64) { if (err.empty()) err = "fused_ln_heads: q | k | v of heads x 64 rows expected"; return LinW{}; }
+    std::vector<float> o(r.size());
+    for (int h = 0; h < heads; ++h)
+      for (int part = 0; part < 3; ++part)
+        memcpy(&o[((size_t)(3 * h + part) * 64) * K], &r[((size_t)part * C + (size_t)h * 64) * K], (size_t)64 * K * 4);
+    return fold_ln(o, {}, 3 * C, K, norm);
+  }
   LinW geglu_ln(const std::string& p, const std::string& norm) {
     const HostTensor* w = get(p + ".weight"); const HostTensor* b = get(p + ".bias");
     if (!w || !b) return LinW{};

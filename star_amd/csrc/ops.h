@@ -10,7 +10,7 @@ namespace star {
 struct ProfScope {
   Ctx* ctx; int idx = -1;
   ProfScope(Ctx* c, int kind, double flops, double bytes, int d0 = 0, int d1 = 0, int d2 = 0, int d3 = 0) : ctx(c) {
-    if (!c->profiling) return;
+    if (!c->profiling || !((c->prof_mask >> kind) & 1u)) return;
     ProfRec r{kind, flops, bytes, rt::event_record(c->stream), nullptr, d0, d1, d2, d3};
     c->prof.push_back(r);
     idx = (int)c->prof.size() - 1;
@@ -60,6 +60,17 @@ struct TAttnArgs {
   float scale = 0.125f;
 };
 int op_temporal_attn(Ctx* ctx, const TAttnArgs& a);
+
+// q | k | v projection (LayerNorm folded: rowab / colsum / bias) + attention over the frame axis in one kernel (gemm_tq.h): level-0 width
+// (C = 320, 5 heads), F <= 32 frames.  W: [960][320] with its 64-row tiles ordered (q_h, k_h, v_h) per head; bias / colsum in that order.
+struct TqArgs {
+  const void* A = nullptr; const void* W = nullptr; void* O = nullptr;
+  const float* bias = nullptr; const float* colsum = nullptr; const float* rowab = nullptr;
+  int lda = 0, ldo = 0, HW = 0, F = 0, C = 320, heads = 5;
+  float scale = 0.125f;
+};
+bool temporal_qkv_attn_covers(int C, int heads, int F);
+int op_temporal_qkv_attn(Ctx* ctx, const TqArgs& a);
 
 // GroupNorm(32 groups) over channels-last rows; rows_per_stat = H*W (per frame) or F*H*W (whole chunk)
 int op_group_norm(Ctx* ctx, const void* x, int ldx, void* y, int ldy, const float* gamma, const float* beta,

@@ -7,6 +7,7 @@
 // tokens by (frame, y, x), temporal kernels stride over frames by H*W rows.
 #include "unet.h"
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace star {
@@ -55,6 +56,10 @@ struct UBuilder : Builder {
     } else {
       t.qkv2 = fused_ln({p + ".attn2.to_q", p + ".attn2.to_k", p + ".attn2.to_v"}, p + ".norm2");
       t.local2 = raw_f32(p + ".local2.conv1.weight");
+      if (t.qkv1.K == 320 && t.qkv1.N == 960) {   // level-0 width: head-ordered copies for the fused projection + attention kernel
+        t.qkv1_tq = fused_ln_heads({p + ".attn1.to_q", p + ".attn1.to_k", p + ".attn1.to_v"}, p + ".norm1", 5);
+        t.qkv2_tq = fused_ln_heads({p + ".attn2.to_q", p + ".attn2.to_k", p + ".attn2.to_v"}, p + ".norm2", 5);
+      }
     }
     t.out2 = linear(p + ".attn2.to_out.0");
     t.ff1 = geglu_ln(p + ".ff.net.0.proj", p + ".norm3");
@@ -209,6 +214,7 @@ struct Fwd : Runner {
 
   // TemporalTransformer.forward + BasicTransformerBlock temp branch (unet_v2v.py:1034-1092, 479-490)
   Act temporal_transformer(const TTW& s, Act x) {
+    static const bool use_tq = std::getenv("STAR_NO_TQ") == nullptr;   // A/B switch, read once
     const int R = rows(x), C = s.C, I = s.inner, HW = x.H * x.W;
     const TBlockW& tb = s.tb;
     // GroupNorm over the whole chunk (no activation) feeds only proj_in: folded into its weights (norm.h: gn_fold_weights_kernel) --
@@ -229,11 +235,20 @@ struct Fwd : Runner {
     for (int pass = 0; pass < 2; ++pass) {
       // temporal LIEM gate + LayerNorm, folded into the QKV projection
       ln_rows(cur.p(), ab.as<float>(), R, I, LN_GATE_LINEAR, (const float*)(pass == 0 ? tb.local1.p : tb.local2.p));
+      const LinW& tq = pass == 0 ? tb.qkv1_tq : tb.qkv2_tq;
+      if (use_tq && tq.w.p && temporal_qkv_attn_covers(I, s.heads, F)) {
+        // projection + attention in one kernel (gemm_tq.h): q | k | v never reach HBM; bit-identical to the two kernels below
+        TqArgs a;
+        a.A = cur.p(); a.lda = I; a.W = tq.w.p; a.bias = (const float*)tq.b.p; a.colsum = (const float*)tq.colsum.p; a.rowab = ab.as<float>();
+        a.O = l.p(); a.ldo = I; a.HW = HW; a.F = F; a.C = I; a.heads = s.heads; a.scale = 0.125f;
+        ok(op_temporal_qkv_attn(ctx, a));
+      } else {
       gemm_ln(cur.p(), I, R, pass == 0 ? tb.qkv1 : tb.qkv2, ab.as<float>(), qkv.p, 3 * I);
       TAttnArgs a;
       a.Q = qkv.p; a.K = (char*)qkv.p + (size_t)I * es; a.V = (char*)qkv.p + (size_t)2 * I * es; a.O = l.p();
       a.ldq = a.ldk = a.ldv = 3 * I; a.ldo = I; a.F = F; a.HW = HW; a.heads = s.heads; a.scale = 0.125f;
       ok(op_temporal_attn(ctx, a));
+      }
       Act nx = make(I, x.H, x.W);
       gemm(l.p(), I, R, pass == 0 ? tb.out1 : tb.out2, nx.p(), I, cur.p(), I);
       cur = std::move(nx);

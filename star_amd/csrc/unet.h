@@ -29,6 +29,8 @@ struct TBlockW {
   NormW n1, n2, n3;
   LinW qkv1, out1;       // self attention (fused q|k|v rows)
   LinW q2, kv2, qkv2, out2;  // spatial: q2 + kv2 (context); temporal: qkv2 (self)
+  LinW qkv1_tq, qkv2_tq;  // temporal blocks of width 320: the same projections with their 64-row tiles ordered (q_h, k_h, v_h) per head, for
+                          // the fused projection + attention kernel (gemm_tq.h); empty elsewhere
   LinW ff1, ff2;         // ff1 GEGLU-interleaved
   DevW local1, local2;   // fp32 LIEM gate weights
 };

@@ -58,6 +58,15 @@ class StarError(RuntimeError):
     pass
 
 
+class TqDesc(ctypes.Structure):
+    _fields_ = [
+        ("A", ctypes.c_void_p), ("W", ctypes.c_void_p), ("O", ctypes.c_void_p),
+        ("bias", ctypes.c_void_p), ("colsum", ctypes.c_void_p), ("rowab", ctypes.c_void_p),
+        ("lda", ctypes.c_int32), ("ldo", ctypes.c_int32), ("HW", ctypes.c_int32), ("F", ctypes.c_int32),
+        ("C", ctypes.c_int32), ("heads", ctypes.c_int32), ("scale", ctypes.c_float),
+    ]
+
+
 class GemmDesc(ctypes.Structure):
     _fields_ = [
         ("A", ctypes.c_void_p), ("W", ctypes.c_void_p), ("C", ctypes.c_void_p),
@@ -108,6 +117,7 @@ class Library:
         f32 = ctypes.c_float
         self.attn_fwd = _sig(c, "star_attn_fwd", i32, vp, ctypes.POINTER(AttnDesc))
         self.temporal_attn_fwd = _sig(c, "star_temporal_attn_fwd", i32, vp, ctypes.POINTER(TAttnDesc))
+        self.temporal_qkv_attn = _sig(c, "star_temporal_qkv_attn", i32, vp, ctypes.POINTER(TqDesc))
         self.group_norm = _sig(c, "star_group_norm", i32, vp, vp, i32, vp, i32, vp, vp, i32, i32, i32, f32, i32)
         self.layer_norm = _sig(c, "star_layer_norm", i32, vp, vp, i32, vp, i32, vp, vp, i32, i32, f32, i32, vp, vp, i32, i32)
         self.layer_norm_rowab = _sig(c, "star_layer_norm_rowab", i32, vp, vp, i32, vp, i32, i32, f32, i32, vp, vp, i32, i32)
@@ -125,6 +135,7 @@ class Library:
         self.color_fix_u8 = _sig(c, "star_color_fix_u8", i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32)
         self.adain_color_fix = _sig(c, "star_adain_color_fix", i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32)
         self.profile_begin = _sig(c, "star_profile_begin", i32, vp)
+        self.profile_begin_kinds = _sig(c, "star_profile_begin_kinds", i32, vp, ctypes.c_uint32)
         self.profile_end = _sig(c, "star_profile_end", i32, vp, ctypes.POINTER(ProfEntry))
 
 
@@ -208,8 +219,15 @@ class Context:
         if not self.lib.is_hostemu:
             self.lib.set_stream(self.h, ctypes.c_void_p(torch.cuda.current_stream(self.device_index).cuda_stream))
 
-    def profile_begin(self):
-        self._check(self.lib.profile_begin(self.h), "profile_begin")
+    def profile_begin(self, kinds=None):
+        """HIP events around every launch, or only around the families named in `kinds` (PROF_KINDS names): events cost stream time"""
+        if kinds is None:
+            self._check(self.lib.profile_begin(self.h), "profile_begin")
+        else:
+            mask = 0
+            for k in kinds:
+                mask |= 1 << PROF_KINDS.index(k)
+            self._check(self.lib.profile_begin_kinds(self.h, mask), "profile_begin")
 
     def profile_end(self):
         """-> {family: {ms, flops, bytes, launches, max_flops, max_flops_ms}} measured with HIP events on the launch stream."""
@@ -299,6 +317,22 @@ class Context:
         d.F, d.HW, d.heads = F_, HW, heads
         d.scale = float(scale if scale is not None else 64 ** -0.5)
         self._check(self.lib.temporal_attn_fwd(self.h, ctypes.byref(d)), "temporal_attn_fwd")
+        return out
+
+    def temporal_qkv_attn(self, x, W_heads, bias, colsum, rowab, F_, HW, heads=5, out=None, scale=None):
+        """q | k | v projection (LayerNorm folded) + attention over the frame axis in one kernel (gemm_tq.h): x [F*HW, 320] token rows,
+        W_heads [960, 320] with 64-row tiles ordered (q_h, k_h, v_h) per head -> O [F*HW, 320]."""
+        self._chk_tensor(x, self.dtype); self._chk_tensor(W_heads, self.dtype)
+        for t in (bias, colsum, rowab):
+            self._chk_tensor(t, torch.float32)
+        C = x.shape[1]
+        if out is None:
+            out = torch.empty(F_ * HW, C, dtype=self.dtype, device=self.torch_device)
+        d = TqDesc()
+        d.A, d.W, d.O, d.bias, d.colsum, d.rowab = x.data_ptr(), W_heads.data_ptr(), out.data_ptr(), bias.data_ptr(), colsum.data_ptr(), rowab.data_ptr()
+        d.lda, d.ldo, d.HW, d.F, d.C, d.heads = x.stride(0), out.stride(0), HW, F_, C, heads
+        d.scale = float(scale if scale is not None else 64 ** -0.5)
+        self._check(self.lib.temporal_qkv_attn(self.h, ctypes.byref(d)), "temporal_qkv_attn")
         return out
 
     def group_norm(self, x, gamma, beta, rows_per_stat, eps=1e-5, silu=False, out=None):

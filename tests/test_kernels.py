@@ -553,6 +553,41 @@ def test_temporal_attention(ctx, dtype, Fr, HW, heads):
     assert_close(out, ref, dtype, what="temporal attn")
 
 
+@pytest.mark.parametrize("Fr,HW", [(32, 19), (16, 8), (5, 3), (32, 64), (1, 9)])
+def test_temporal_projection_and_attention_fused(ctx, dtype, Fr, HW):
+    """gemm_tq.h: the q | k | v projection of a temporal attention (LayerNorm folded: STAR_EPI_ROWAFF operands) and the attention over
+    the frame axis in ONE kernel at the level-0 width (C = 320, 5 heads; unet_v2v.py:479-489) -- q | k | v stay in the wave's staging
+    block.  Bit for bit the two-kernel path (star_gemm with the folded LayerNorm, then star_temporal_attn_fwd), and close to an fp32
+    statement of LayerNorm -> Linear -> attention; ragged pixel counts (a workgroup covers 8 pixels), fewer than 32 frames (masked
+    keys, unstored queries)."""
+    g = torch.Generator().manual_seed(Fr * 37 + HW)
+    C, heads = 320, 5
+    M = Fr * HW
+    x = (torch.randn(M, C, generator=g) * 1.3 + 0.2).to(dtype)
+    Wq, Wk, Wv = ((torch.randn(C, C, generator=g) / math.sqrt(C)) for _ in range(3))
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1
+    Wf = (torch.cat([Wq, Wk, Wv]) * gamma[None]).to(dtype)                      # W' = gamma o W, rows q | k | v
+    cb = (torch.cat([Wq, Wk, Wv]) @ beta).contiguous()                           # c_n = sum_k beta_k W[n][k] (no bias in to_q / to_k / to_v)
+    cs = Wf.float().sum(1).contiguous()
+    perm = torch.cat([torch.arange(64) + part * C + h * 64 for h in range(heads) for part in range(3)])   # (q_h, k_h, v_h) per head
+    xd = dev(ctx, x)
+    rowab = ctx.layer_norm_rowab(xd, eps=1e-5)
+    # two kernels: the A-stationary K = 320 kernel (what the level-0 layers run: its row-affine epilogue and the tiled kernel's differ
+    # by an fp32 rounding of the affine on hardware, 1 ulp of the 16-bit output), then the attention over frames
+    qkv = ctx.gemm(xd, dev(ctx, Wf), bias=dev(ctx, cb), rowab=rowab, colsum=dev(ctx, cs), force_tile=30)
+    two = ctx.temporal_attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], Fr, HW, heads)
+    # one kernel
+    one = ctx.temporal_qkv_attn(xd, dev(ctx, Wf[perm].contiguous()), dev(ctx, cb[perm].contiguous()), dev(ctx, cs[perm].contiguous()), rowab, Fr, HW)
+    assert one.shape == (M, C) and torch.equal(one, two)
+    # fp32 statement
+    h = F.layer_norm(x.float(), (C,), gamma, beta, 1e-5)
+    tr = lambda t: t.reshape(Fr, HW, heads, 64).permute(1, 2, 0, 3)
+    ref = F.scaled_dot_product_attention(tr(h @ Wq.t()), tr(h @ Wk.t()), tr(h @ Wv.t())).permute(2, 0, 1, 3).reshape(M, C)
+    assert_close(one, ref, dtype, scale=12.0, what="fused temporal projection + attention")
+    with pytest.raises(L.StarError):     # more than 32 frames per chunk keep the two kernels
+        ctx.temporal_qkv_attn(xd, dev(ctx, Wf[perm].contiguous()), dev(ctx, cb[perm].contiguous()), dev(ctx, cs[perm].contiguous()), rowab, 33, HW)
+
+
 @pytest.mark.parametrize("C", [320, 128, 2560, 960, 512, 1920])
 @pytest.mark.parametrize("silu", [False, True])
 def test_group_norm(ctx, dtype, C, silu):
