@@ -312,7 +312,8 @@ def main():
         a = prof_u["attn_self"]
         l0_flops = a["max_flops"]                       # the largest launches = the L0 layers (N = H*W of the padded latent)
         traffic = None
-        tname = "r03_attn_v5_traffic.json"
+        tname = next((n for n in ("r04_attn_v5_traffic.json", "r03_attn_v5_traffic.json") if os.path.isfile(os.path.join(ROOT, "profiles", n))),
+                     "r04_attn_v5_traffic.json")    # the newest PMC collection of the (unchanged) kernel at this shape
         tpath = os.path.join(ROOT, "profiles", tname)
         if os.path.isfile(tpath) and not args.small and args.config in ("cfg2", "cfg3") and not custom:   # PMC pass of the same kernel at the same shape
             traffic = json.load(open(tpath))["traffic_bytes_per_launch"]

@@ -1,6 +1,7 @@
 """Full-width parity fixture on BASELINE config[1]'s OWN geometry (TEST INFRASTRUCTURE ONLY; needs /root/reference).
 
-    nice python oracle/make_golden_cfg2.py       # ~1 h on 8 cores, ~35 GB of RAM
+    nice python oracle/make_golden_cfg2.py       # 1.14 PFLOP: 4.4 h on 8 shared cores (2.4 h per forward; the CPU flash-attention of the
+                                                 # 7 level-0 layers dominates), ~35 GB of RAM
 
 cfg2 = 32 frames, latent 122x216 (240x426 -> x4 = 960x1704, padded to 976x1728): level sizes 122 -> 62 -> 32 -> 17 rows, the
 5-D GroupNorms and temporal attention over all 32 frames x 26 352 pixels, four temporal blocks per level.  Until round 4 that

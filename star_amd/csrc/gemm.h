@@ -75,10 +75,6 @@ STAR_DEV float gelu_erf(float x) {
 // are VALU-bound (the A-stationary kernel's exceeds what 80 MFMAs shadow; the persistent tile's runs with the matrix pipe idle).
 using f32x2 = vec<float, 2>;
 STAR_DEV f32x2 gelu_erf2(f32x2 x) {
-#ifdef STAR_HOSTEMU
-  f32x2 r; r[0] = gelu_erf(x[0]); r[1] = gelu_erf(x[1]);
-  return r;
-#else
   f32x2 ax, z;
   ax[0] = fabsf(x[0]); ax[1] = fabsf(x[1]);
   z[0] = fminf(ax[0] * 0.70710678118654752440f, 4.5f); z[1] = fminf(ax[1] * 0.70710678118654752440f, 4.5f);
@@ -90,7 +86,6 @@ STAR_DEV f32x2 gelu_erf2(f32x2 x) {
   r[0] = fmaxf(x[0], 0.f) - ax[0] * fast_exp2(p[0]);
   r[1] = fmaxf(x[1], 0.f) - ax[1] * fast_exp2(p[1]);
   return r;
-#endif
 }
 STAR_DEV f32x4 gelu_erf4(f32x4 x) {
   f32x2 a = {x[0], x[1]}, b = {x[2], x[3]};
@@ -151,7 +146,9 @@ gemm_kernel(const GemmParams p) {
     tile_m = g * p.group_m + in % rows;
     tile_n = in / rows;
   }
-  const int m0 = p.m_off + tile_m * BM, n0 = tile_n * BN;
+  tile_m += p.m_off / BM;   // (a multiple of BM by construction; added to the tile index so that m0 stays a provable multiple of BM --
+                            // as "p.m_off + tile_m * BM" the 256 x 320 and 128 x 320 residual flavours spilled 1-5 registers)
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   if constexpr (!F32OUT) {   // this tile's bias slice, read from LDS in the epilogue (visible after the main loop's barriers)
     float* bl = reinterpret_cast<float*>(smem + SMEM_LOOP);

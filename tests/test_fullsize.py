@@ -1,5 +1,6 @@
 """BASELINE config[1] sizes (32 frames, latent 122 x 216, the full 2.04 B-parameter architecture) on hardware: properties that
-do not need a CPU oracle (the fp32 CPU path would take hours at this size)."""
+do not need a CPU oracle (the fp32 CPU path takes hours at this size: the one reference CFG pair that was afforded is the fixture of
+tests/test_parity_cfg2.py)."""
 import math
 
 import pytest
@@ -116,28 +117,5 @@ def test_vae_mid_attention_at_its_real_block_size(monkeypatch):
     vae.ctx.sync()
 
 
-@pytest.mark.gpu
-def test_full_model_forward_pair_at_cfg2_size():
-    """the whole denoiser at cfg2 size: finite, the shared-prefix CFG pair is bit-identical to two plain forwards, and the
-    two text contexts give different predictions."""
-    from star_amd.modules.unet_v2v import ControlledV2VUNet
-    from star_amd.topology import UNetConfig, random_state_dict
-    cfg = UNetConfig()
-    net = ControlledV2VUNet(cfg, dtype=torch.float16, device=0)
-    net.load_state_dict(random_state_dict(cfg, seed=0))
-    net.release_host_weights()
-    g = torch.Generator().manual_seed(1)
-    f, h, w = 32, 122, 216
-    x = torch.randn(1, 4, f, h, w, generator=g).cuda()
-    hint = (torch.randn(1, 4, f, h, w, generator=g) * 0.5).cuda()
-    y = torch.randn(1, 77, 1024, generator=g).cuda()
-    y2 = torch.randn(1, 77, 1024, generator=g).cuda()
-    t = torch.tensor([500])
-    a = net(x, t=t, y=y, hint=hint)
-    pa, pb = net.forward_cfg_pair(x, t, y, y2, hint=hint)
-    assert a.shape == x.shape and torch.isfinite(pa).all() and torch.isfinite(pb).all()
-    assert torch.equal(a, pa)
-    b = net(x, t=t, y=y2, hint=hint)
-    assert torch.equal(b, pb)
-    assert float((pa - pb).abs().mean()) > 0
-    assert 1e-3 < float(pa.std()) < 1e3 and not math.isnan(float(pa.mean()))
+# (the whole denoiser at cfg2 size -- finite, shared-prefix CFG pair == two plain forwards -- is asserted AGAINST THE REFERENCE in
+# tests/test_parity_cfg2.py since round 4; rounds 1-3 compared that shape only with itself here)
