@@ -561,13 +561,15 @@ def test_temporal_attention(ctx, dtype, Fr, HW, heads):
     assert_close(out, ref, dtype, what="temporal attn")
 
 
-@pytest.mark.parametrize("Fr,HW", [(32, 19), (16, 8), (5, 3), (32, 64), (1, 9)])
+@pytest.mark.parametrize("Fr,HW", [(32, 11), (16, 8), (5, 3), (32, 64), (1, 9)])
 def test_temporal_projection_and_attention_fused(ctx, dtype, Fr, HW):
     """gemm_tq.h: the q | k | v projection of a temporal attention (LayerNorm folded: STAR_EPI_ROWAFF operands) and the attention over
     the frame axis in ONE kernel at the level-0 width (C = 320, 5 heads; unet_v2v.py:479-489) -- q | k | v stay in the wave's staging
     block.  Bit for bit the two-kernel path (star_gemm with the folded LayerNorm, then star_temporal_attn_fwd), and close to an fp32
     statement of LayerNorm -> Linear -> attention; ragged pixel counts (a workgroup covers 8 pixels), fewer than 32 frames (masked
     keys, unstored queries)."""
+    if Fr * HW > 400 and ctx.lib.is_hostemu:
+        pytest.skip("hardware-only size (the emulator runs 15 projection tiles of 320 k-elements per workgroup)")
     g = torch.Generator().manual_seed(Fr * 37 + HW)
     C, heads = 320, 5
     M = Fr * HW

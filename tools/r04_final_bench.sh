@@ -19,6 +19,8 @@ for tree in r03 r04; do
 done
 cat $AB
 cd $GRAFT_REPO_ROOT
+( timeout 400 python -m pytest tests/test_dit.py tests/test_embedder.py tests/test_pipeline.py -q -m gpu -s -k "real_size or full_size or hf_clip or own_bf16 or own_fp16" 2>&1 | grep -v amdgpu.ids | grep -E "rel rms|relative rms|passed|failed" ) > $OUT/pytest_parity_lines.txt 2>&1
+cat $OUT/pytest_parity_lines.txt
 timeout 900 python bench.py --steps 1 --warmup 1 > $OUT/bench_final_f16_n1.json 2> $OUT/bench.err
 head -c 500 $OUT/bench_final_f16_n1.json; echo
 cd /tmp && export TMPDIR=/tmp
