@@ -126,8 +126,8 @@ static int launch_gemm(Ctx* ctx, const GemmArgs& a) {
   // ---- tail split.  The big tiles run ONE workgroup per CU, so a launch is ceil(tiles / CUs) rounds and the last round can be mostly
   // empty: the 1280-wide layers of level 2 (M = 55296: 864 tiles of 256 x 320 = 3.4 rounds, 1080 of 256 x 256 = 4.2) spent 16 % of
   // their time with three quarters of the chip idle.  When the last round is poorly filled, the launch covers only the tile rows of
-  // the FULL rounds and the remaining rows go to a second launch of half-height tiles (128 x 320 where the width allows, else 128 x 128: two workgroups per CU, same
-  // k order per output -- bit-identical).  Decided by a cost model in units of one big tile's time.
+  // the FULL rounds and the remaining rows go to a second launch of 128 x 128 tiles (tile 3: two workgroups per CU, every mode and
+  // epilogue flavour, same k order per output -- bit-identical).  Decided by a cost model in units of one big tile's time.
   if (!a.force_tile && a.m_off == 0 && a.m_end == 0 && (tile == 1 || tile == 2 || tile == 17)) {   // (the persistent tile 18 is only chosen where its rounds are full)
     const int cus = a.assume_cus > 0 ? a.assume_cus : (ctx->num_cus > 0 ? ctx->num_cus : 256);
     const int bm = 256, bn = tile == 2 ? 320 : 256;
@@ -136,17 +136,16 @@ static int launch_gemm(Ctx* ctx, const GemmArgs& a) {
     if (full >= 1 && nt % cus != 0) {
       const long long main_rows_t = full * cus / tn;      // tile rows of the main launch (its tiles fit `full` rounds)
       const long long rem_rows = a.M - main_rows_t * bm;
-      // the remainder's tile: 128 x 320 (tile 10: two 4-wave workgroups per CU) where the width is a multiple of 320 and the epilogue
-      // is one that tile has (bias / residual), else 128 x 128 (tile 3: every flavour)
-      const bool wide_rem = a.N % 320 == 0 && !(a.epi & (EPI_ROWAFF | EPI_GELU_TANH | EPI_GEGLU | EPI_OUT_F32));
-      const int rbn = wide_rem ? 320 : 128, rtile = wide_rem ? 10 : 3;
+      // the remainder's tile is 128 x 128 (tile 3: every mode and flavour).  The 128 x 320 tile 10 was tried as the remainder of the
+      // 320-multiple widths and made the split layers 6-9 % SLOWER than unsplit (its 32-deep ring loop; profiles/r04_same_box_r03_vs_r04.txt)
+      const int rbn = 128, rtile = 3;
       const long long ns = ((rem_rows + 127) / 128) * ((a.N + rbn - 1) / rbn);
       const double small_work = 128.0 * rbn / ((double)bm * bn);            // one remainder tile in units of a big one
       double rem_t = (double)ns * small_work / cus;                         // remainder work per CU ...
       if (rem_t < small_work) rem_t = small_work;                           // ... never less than one remainder tile
-      rem_t /= wide_rem ? 0.8 : 0.6;                                        // relative rate of the remainder tiles (measured: the 128 x 128 ones cost about one big-tile time per round)
+      rem_t /= 0.6;                                                         // the 128 x 128 tiles run at ~0.6 of the big tiles' rate
       const double t_split = (double)((main_rows_t * tn + cus - 1) / cus) + rem_t, t_plain = (double)((nt + cus - 1) / cus);
-      if (main_rows_t >= 1 && rem_rows > 0 && t_split < (wide_rem ? 0.97 : 0.95) * t_plain) {
+      if (main_rows_t >= 1 && rem_rows > 0 && t_split < 0.95 * t_plain) {
         GemmArgs m = a, r = a;
         m.force_tile = tile; m.m_end = (int)(main_rows_t * bm);
         r.force_tile = rtile; r.m_off = (int)(main_rows_t * bm);

@@ -264,14 +264,14 @@ def test_gemm_tail_split_is_bit_identical(ctx, dtype):
     split = ctx.gemm(xr, wpd, bias=bd, mode=L.A_CONV3X3, conv=(NB, H, Wd, Cin, H, Wd, 1, 1, 1), force_tile=1008)
     assert torch.equal(whole, split)
     assert_close(split, nhwc_rows(ref), dtype, what="conv3x3 tail split")
-    # the same conv 64 -> 320 channels: 256 x 320 tiles, remainder on 128 x 320 tiles (tile 10) instead of 128 x 128
+    # the same conv 64 -> 320 channels: 256 x 320 tiles (one tile column)
     w3 = (torch.randn(320, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)).to(dtype)
     b3 = torch.randn(320, generator=g)
     w3d, b3d = dev(ctx, w3.permute(0, 2, 3, 1).reshape(320, 9 * Cin).contiguous()), dev(ctx, b3)
     whole = ctx.gemm(xr, w3d, bias=b3d, mode=L.A_CONV3X3, conv=(NB, H, Wd, Cin, H, Wd, 1, 1, 1), force_tile=2)
     split = ctx.gemm(xr, w3d, bias=b3d, mode=L.A_CONV3X3, conv=(NB, H, Wd, Cin, H, Wd, 1, 1, 1), force_tile=1008)
     assert torch.equal(whole, split)
-    assert_close(split, nhwc_rows(F.conv2d(x.float(), w3.float(), b3, padding=1)), dtype, what="conv3x3 tail split, 128 x 320 remainder")
+    assert_close(split, nhwc_rows(F.conv2d(x.float(), w3.float(), b3, padding=1)), dtype, what="conv3x3 tail split, 256 x 320 main tiles")
     x4 = torch.randn(35, Cin, H, Wd, generator=g).to(dtype)           # Downsample: 35 frames -> 35 x 12 x 10 = 4200 output rows
     ref = F.conv2d(x4.float(), w.float(), b, stride=2, padding=(2, 1))
     Ho, Wo = ref.shape[2:]
