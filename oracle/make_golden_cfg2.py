@@ -48,7 +48,9 @@ def cfg2_inputs(cfg=CFG2):
     return z, eps, y, neg
 
 
-def main():
+def main(t_eval=None, out_name="cfg2_pair.pt"):
+    """t_eval: timestep of the pair (default CFG2['t'] = 899, the first evaluation; `python oracle/make_golden_cfg2.py 449` writes the
+    mid-trajectory fixture cfg2_pair_t449.pt from the same z / eps / contexts)"""
     import ref_loader
     from star_amd.topology import UNetConfig, random_state_dict
     torch.set_grad_enabled(False)
@@ -64,7 +66,8 @@ def main():
     z, eps, y, neg = cfg2_inputs()
     sig = sch.noise_schedule(schedule="logsnr_cosine_interp", n=1000, zero_terminal_snr=True, scale_min=2.0, scale_max=4.0)
     gd = dif.GaussianDiffusion(sigmas=sig)
-    t = torch.LongTensor([CFG2["t"]])
+    cfg = dict(CFG2, t=int(t_eval)) if t_eval is not None else dict(CFG2)
+    t = torch.LongTensor([cfg["t"]])
     xt = gd.diffuse(z, t, noise=eps)
     raw = []
 
@@ -76,11 +79,14 @@ def main():
 
     x0 = gd.denoise(xt, t, None, model, [{"y": y}, {"y": neg}, {"hint": z}], CFG2["guide_scale"], CFG2["guide_rescale"])[-2]
     assert len(raw) == 2 and torch.isfinite(x0).all()
-    torch.save({"cfg": CFG2, "x0": x0.clone(), "y_out_f16": raw[0].to(torch.float16), "u_out_f16": raw[1].to(torch.float16),
+    torch.save({"cfg": cfg, "x0": x0.clone(), "y_out_f16": raw[0].to(torch.float16), "u_out_f16": raw[1].to(torch.float16),
                 "xt_sum": float(xt.double().sum()), "x0_range": (float(x0.min()), float(x0.max()))},
-               os.path.join(GOLD, "cfg2_pair.pt"))
-    print("wrote cfg2_pair.pt", tuple(x0.shape), time.time() - t0)
+               os.path.join(GOLD, out_name))
+    print("wrote", out_name, tuple(x0.shape), time.time() - t0)
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1:
+        main(int(sys.argv[1]), f"cfg2_pair_t{int(sys.argv[1])}.pt")
+    else:
+        main()
