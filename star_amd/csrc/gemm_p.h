@@ -15,8 +15,10 @@
 //   * the first K tile of an output tile starts its accumulators with zero-C MFMAs (no 256 v_mov);
 //   * the epilogue is WAVE-PRIVATE: a wave converts its own 128 x 128 block in 32 x 64 units through a private, XOR-swizzled
 //     4 KB LDS block and stores whole 128-byte lines -- no workgroup barrier, no shared staging area under the K loop's stages;
-//     the other three waves are already in the next tile's K loop (they meet again at its first barrier), and the next tile's
-//     operands land meanwhile.  Bias / column-sum slices arrive by 4-byte LDS-DMA into a slot per tile parity.
+//     the waves meet again at the next tile's first barrier, and the next tile's operands land meanwhile.  (The four waves of a
+//     workgroup reach their epilogues together, so the matrix pipe idles for it: 2.8 us per output tile plain, 4.9 with the folded
+//     LayerNorm, ~6 with GEGLU -- the epilogue is VALU-bound, 961 to 2600 instructions)
+//     Bias / column-sum slices arrive by 4-byte LDS-DMA into a slot per tile parity.
 // LDS: [A stage 0 | A stage 1 | W stage 0 | W stage 1] 128 KB, 4 staging blocks 16 KB, 2 x (bias | colsum) 4 KB = 148 KB.
 #pragma once
 #include "gemm.h"
