@@ -113,8 +113,8 @@ gemm_tq_kernel(const TqParams p) {
     constexpr bool DRAIN = decltype(drain_tag)::value;
     // W tile t has landed.  Its DMA was issued at the start of tile t - 1; behind it only the 8 output stores of a head's attention
     // can be in flight (exactly 8: dead lanes store to an out-of-range offset), and only when the attention ran behind tile t - 1,
-    // i.e. t % 3 == 1: they retire after the DMA, so a counted wait leaves them in flight
-    if (t % 3 == 1) STAR_WAIT_VMCNT_N(8); else STAR_WAIT_VMCNT(0);
+    // i.e. t % 3 == 1 from t = 4 on (behind tile 0 nothing has run yet): they retire after the DMA, so a counted wait leaves them in flight
+    if (t % 3 == 1 && t >= 4) STAR_WAIT_VMCNT_N(8); else STAR_WAIT_VMCNT(0);
     barrier_keep_dma();
     if (t + 1 < NT) stage(t + 1, SL ^ 1);
     {
