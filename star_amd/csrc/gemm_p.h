@@ -344,8 +344,10 @@ gemm_persist_kernel(const GemmParams p) {
   for (int i = 0; i < ntm; ++i) {
     int m0, n0;
     tile_origin(i, m0, n0);
-    // the last two K tiles of the workgroup's stream have nothing (or only W) left to stage: guarded form; all others: steady form
-    const int nks = (i == ntm - 1) ? (nk > 2 ? nk - 2 : 0) : nk;
+    // the last two K tiles of the workgroup's WHOLE stream have nothing (or only W) left to stage: guarded form; all others (stream
+    // index <= ntm * nk - 3): steady form.  (With nk = 1 the last two K tiles belong to two output tiles.)
+    int nks = ntm * nk - 2 - g;           // steady K tiles from this tile's first one on
+    nks = nks < 0 ? 0 : (nks > nk ? nk : nks);
     if (nks > 0) ktile(g & 1, std::true_type{}, std::true_type{}, n0, i & 1);
     else ktile(g & 1, std::true_type{}, std::false_type{}, n0, i & 1);
     ++g;

@@ -184,7 +184,7 @@ def test_temporal_conv(ctx, dtype, Fr, H, Wd, C):
     assert_close(out, ref, dtype, what="tconv")
 
 
-@pytest.mark.parametrize("M,N,K,wgs", [(515, 512, 256, 0), (300, 264, 64, 0), (700, 600, 192, 2), (257, 1288, 128, 3), (1030, 256, 448, 1), (64, 8, 64, 0), (700, 576, 128, 2),
+@pytest.mark.parametrize("M,N,K,wgs", [(515, 512, 256, 0), (300, 264, 64, 0), (700, 600, 192, 2), (257, 1288, 128, 3), (1030, 256, 448, 1), (64, 8, 64, 0), (700, 576, 128, 2), (700, 600, 64, 2),
                                         (2100, 1920, 640, 8)])
 def test_gemm_persistent_tile(ctx, dtype, M, N, K, wgs):
     """tile 18 (gemm_p.h): resident workgroups walk their output tiles, the K tiles of all of them form one LDS-DMA stream (operands
