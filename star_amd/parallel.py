@@ -8,6 +8,10 @@ The path shards along the frame-chunk axis:
     337-350), so `ChunkSharder` gives chunk i to rank i % world and all-gathers the trimmed x0 cores (C2, a few MB)
     so that every rank applies the identical solver update to the full-length latent.  VAE decode groups of 3 frames
     are sharded the same way by `FrameSharder`.
+  * CogVideoX variant (BASELINE config #5): REPLICAS ONLY.  The reference shards its 8 GPUs by prompt / input video -- line `cnt` of
+    the input file goes to data-parallel rank `cnt % world_size` (cogvideox-based/sat/sample_sr.py:38-45,139-141) -- and forces
+    model- and context-parallel size 1 at sampling time (:263-264): the 42-layer DiT over 9676 tokens is never split.
+    `replica_items` is that striding; no collective exists on that path (none is invented here).
 The only collectives are all-gathers: the payload (RCCL over xGMI) and, once per (latent shape, chunk list), two small
 all-gathers of part counts / sizes; no reduce-type collective exists anywhere on the path.
 """
@@ -147,6 +151,22 @@ class FrameSharder:
             for j, i in enumerate(range(r, len(groups), world)):
                 out[i] = per_rank[r][j]
         return torch.cat(out)
+
+
+def replica_items(items, rank=None, world=None, group=None):
+    """Prompt-level data parallelism of the CogVideoX sampler (cogvideox-based/sat/sample_sr.py:38-45: `read_from_file(p, rank,
+    world_size)`): yields `(item, cnt)` for every `cnt` with `cnt % world == rank`, in order; `items` is any iterable (the lines
+    of the prompt file, input videos).  rank / world default to the process group's (1 process: everything).  No collective."""
+    if world is None or rank is None:
+        if dist.is_available() and dist.is_initialized():
+            world, rank = _world(group)
+        else:
+            world, rank = 1, 0
+    if world < 1 or not 0 <= rank < world:
+        raise ValueError(f"replica_items: rank {rank} outside world {world}")
+    for cnt, item in enumerate(items):
+        if cnt % world == rank:
+            yield (item.strip() if isinstance(item, str) else item), cnt
 
 
 def gather_frames(frames, group=None, source=None, ctx=None):

@@ -67,6 +67,10 @@ def _worker(rank, world, port, q):
         clip = torch.full((1, 3, 2, 4, 4), float(rank))
         allc = gather_frames(clip)
         res["gather"] = all(float(allc[r].mean()) == r for r in range(world))
+        # cfg5 (CogVideoX variant): replicas only -- the reference's read_from_file striding, rank / world from the process group
+        from star_amd.parallel import replica_items
+        lines = [f"prompt {i}\n" for i in range(7)]
+        res["replica_items"] = list(replica_items(lines)) == [(f"prompt {i}", i) for i in range(rank, 7, world)]
         q.put((rank, res))
     finally:
         dist.destroy_process_group()
@@ -166,3 +170,17 @@ def test_cfg3_layout_on_eight_ranks():
     assert sorted(r for r, _ in results) == list(range(8))
     for rank, res in results:
         assert all(res.values()), (rank, res)
+
+
+def test_replica_items_is_the_references_prompt_striding():
+    """cogvideox-based/sat/sample_sr.py:38-45: line cnt of the input file goes to rank cnt % world_size, stripped, with its index;
+    every line is owned by exactly one rank; a single process owns everything."""
+    from star_amd.parallel import replica_items
+    lines = ["a\n", " b \n", "c", "d\n", "e\n"]
+    assert list(replica_items(lines)) == [("a", 0), ("b", 1), ("c", 2), ("d", 3), ("e", 4)]
+    got = [list(replica_items(lines, rank=r, world=3)) for r in range(3)]
+    assert got[0] == [("a", 0), ("d", 3)] and got[1] == [("b", 1), ("e", 4)] and got[2] == [("c", 2)]
+    assert sorted(c for g in got for _, c in g) == list(range(5))
+    assert list(replica_items([], rank=0, world=2)) == []
+    with pytest.raises(ValueError):
+        list(replica_items(lines, rank=3, world=3))
