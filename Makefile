@@ -35,7 +35,7 @@ build/emu/hostemu.o: tools/hostemu/hostemu.cpp $(CSRC)/hostemu.h
 	@mkdir -p build/emu
 	$(CLANGXX) $(EMUFLAGS) -c $< -o $@
 tools/hostemu/libstar_emu.so: $(EMU_OBJS)
-	$(CLANGXX) -shared -fPIC $^ -o $@ -lm
+	$(CLANGXX) -shared -fPIC $^ -o $@ -lm -lpthread
 
 # bench-only build: the product sources + timing ablations / losing A/B variants (-DSTAR_BENCH_VARIANTS); loaded explicitly by tools/
 BENCH_OBJS := $(patsubst $(CSRC)/%.cpp,build/bench/%.o,$(SRCS))
