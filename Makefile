@@ -51,8 +51,15 @@ tools/bench/libstar_hip_bench.so: $(BENCH_OBJS)
 	@mkdir -p tools/bench
 	$(HIPCC) --offload-arch=gfx950 -shared -fPIC $^ -o $@
 
+# torch-free timing harness over the C ABI (dlopen()s a build of the library): seconds instead of minutes per A/B on a fresh GPU box
+cbench: tools/cbench/cbench tools/cbench/cbench_emu
+tools/cbench/cbench: tools/cbench/cbench.cpp include/star_hip.h
+	$(HIPCC) -O2 --offload-arch=gfx950 $< -o $@ -ldl
+tools/cbench/cbench_emu: tools/cbench/cbench.cpp include/star_hip.h
+	g++ -O2 -DCBENCH_EMU $< -o $@ -ldl
+
 -include $(wildcard build/hip/*.d build/emu/*.d build/bench/*.d)
 
 clean:
-	rm -rf build star_amd/libstar_hip.so tools/hostemu/libstar_emu.so tools/bench
-.PHONY: all hip emu bench clean
+	rm -rf build star_amd/libstar_hip.so tools/hostemu/libstar_emu.so tools/bench tools/cbench/cbench tools/cbench/cbench_emu
+.PHONY: all hip emu bench cbench clean
