@@ -27,6 +27,20 @@ static int launch_astat(Ctx* ctx, const GemmArgs& a) {
   if (a.force_tile == 33) { STAR_LAUNCH((gemm_astat_kernel<T, 0, 3>), grid, block, smem, ctx->stream, p); return 0; }
   if (a.force_tile == 34) { STAR_LAUNCH((gemm_astat_kernel<T, 0, 4>), grid, block, smem, ctx->stream, p); return 0; }
   if (a.force_tile == 35) { STAR_LAUNCH((gemm_astat_kernel<T, 0, 5>), grid, block, smem, ctx->stream, p); return 0; }
+  // scheduling variants (correct results, bit-identical): 36 / 37 = ILV 1 / 2 (sched_group_barrier interleave of the epilogue with the
+  // MFMAs: half units per step / whole units over a pair of steps), 38 / 39 / 40 = the same placements 1 / 0 / 2 with the GELU
+  // polynomial as scalar v_fma_f32 (which overlap a wave's own MFMAs; v_pk_fma_f32 do not)
+  if (a.force_tile >= 36 && a.force_tile <= 40) {
+    const bool g = (a.epi & EPI_GEGLU) != 0;
+    switch (a.force_tile) {
+      case 36: if (g) STAR_LAUNCH((gemm_astat_kernel<T, 1, 0, 1>), grid, block, smem, ctx->stream, p); else STAR_LAUNCH((gemm_astat_kernel<T, 0, 0, 1>), grid, block, smem, ctx->stream, p); break;
+      case 37: if (g) STAR_LAUNCH((gemm_astat_kernel<T, 1, 0, 2>), grid, block, smem, ctx->stream, p); else STAR_LAUNCH((gemm_astat_kernel<T, 0, 0, 2>), grid, block, smem, ctx->stream, p); break;
+      case 38: if (g) STAR_LAUNCH((gemm_astat_kernel<T, 1, 0, 3>), grid, block, smem, ctx->stream, p); else return ctx->fail("gemm (A-stationary): tiles 38-40 are GEGLU variants"); break;
+      case 39: if (g) STAR_LAUNCH((gemm_astat_kernel<T, 1, 0, 4>), grid, block, smem, ctx->stream, p); else return ctx->fail("gemm (A-stationary): tiles 38-40 are GEGLU variants"); break;
+      default: if (g) STAR_LAUNCH((gemm_astat_kernel<T, 1, 0, 5>), grid, block, smem, ctx->stream, p); else return ctx->fail("gemm (A-stationary): tiles 38-40 are GEGLU variants"); break;
+    }
+    return 0;
+  }
 #else
   if (a.force_tile > 30) return ctx->fail("gemm (A-stationary): ablation ids exist only in the bench build");
 #endif

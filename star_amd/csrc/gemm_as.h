@@ -22,7 +22,11 @@ namespace star {
 
 // ABL (bench builds, timing only, wrong results): 1 no epilogue, 2 no W staging / barrier after tile 0, 3 W fragments not re-read,
 // 4 = 1 + 2 (the k loop alone: MFMAs + W fragment reads), 5 = 4 + 3 (MFMAs alone)
-template <class T, int GEGLU, int ABL = 0>
+// ILV: the epilogue pieces are INTERLEAVED with the MFMAs of a k-step by sched_group_barrier patterns (1 MFMA, then a share of the
+// step's VALU) instead of being left to the scheduler, which clusters them (ISA of the ILV = 0 GEGLU loop: 8 MFMAs back to back, then
+// ~75 VALU with the matrix pipe idle -- 560 cycles per two k-steps where max(MFMA, VALU) is 380); GEGLU units are split in two halves
+// (one per k-step) so that every step carries VALU work.  Same instructions, same arithmetic: bit-identical.
+template <class T, int GEGLU, int ABL = 0, int ILV = 0>
 STAR_GLOBAL void STAR_LAUNCH_BOUNDS(256, 1)
 gemm_astat_kernel(const GemmParams p) {
   constexpr int K = 320, KS = K / 16, SLAB = 64 * 128, WTILE = (K / 64) * SLAB;   // 40 KB per 64-row W tile
@@ -30,6 +34,12 @@ gemm_astat_kernel(const GemmParams p) {
   char* smem = dyn_smem();
   char* stg = smem + 2 * WTILE + wave_uniform((int)threadIdx.x >> 6) * STG;
   float* bias_lds = reinterpret_cast<float*>(smem + 2 * WTILE + 4 * STG);   // bias[N] | colsum[N]
+  // ILV >= 3: the GELU polynomial as scalar v_fma_f32 instead of v_pk_fma_f32.  Measured (tools/probe/mfma_valu_overlap.hip,
+  // profiles/r04_probe_mfma_valu_overlap.txt): a wave's v_fma_f32 ride in the shadow of its own MFMAs (4 per MFMA for free, 4.3
+  // cycles each beyond), its v_pk_fma_f32 do NOT (MFMA + 16 + 4.4 cycles each, no overlap at all) -- packed fp32 only pays where no
+  // MFMA is in flight.  ILV 3 = 1 + scalar, 4 = 0 + scalar, 5 = 2 + scalar.
+  constexpr bool SCALAR = ILV >= 3;
+  constexpr int ILVP = ILV >= 3 ? (ILV == 3 ? 1 : ILV == 4 ? 0 : 2) : ILV;   // the placement pattern
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = wave_uniform(tid >> 6);
   const int h2 = lane >> 5, lq = lane & 31;
@@ -117,6 +127,10 @@ gemm_astat_kernel(const GemmParams p) {
       f32x4 gt;
 #pragma unroll
       for (int e = 0; e < 4; ++e) gt[e] = ra[rb] * STAR_ACC(P)[rb][1][g * 4 + e] + (rbv[rb] * egs[U & 1][e] + egb[U & 1][e]);
+      if constexpr (SCALAR) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] * gelu_erf(gt[e]);
+      } else
       v = v * gelu_erf4(gt);
     }
     vec<T, 4> o;
@@ -126,6 +140,32 @@ gemm_astat_kernel(const GemmParams p) {
     const int c = (GEGLU ? P * 4 : cb * 4) + g;
     const int row = rb * 32 + lq;
     *reinterpret_cast<vec<T, 4>*>(stg + row * 128 + ((c ^ (row & 7)) << 4) + h2 * 8) = o;
+  };
+  // GEGLU, ILV: half a unit (2 of the quad's 4 columns) per k-step; the packed pair of the first half waits in a register for the second
+  vec<T, 2> o_lo;
+  auto epi_half = [&](auto ptag, auto utag, auto htag) STAR_ALWAYS_INLINE {
+    constexpr int P = decltype(ptag)::value, U = decltype(utag)::value, H = decltype(htag)::value;
+    constexpr int rb = U / 4, g = U % 4;
+    f32x2 v, gt;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      v[e] = ra[rb] * STAR_ACC(P)[rb][0][g * 4 + 2 * H + e] + (rbv[rb] * ecs[U & 1][2 * H + e] + ecb[U & 1][2 * H + e]);
+      gt[e] = ra[rb] * STAR_ACC(P)[rb][1][g * 4 + 2 * H + e] + (rbv[rb] * egs[U & 1][2 * H + e] + egb[U & 1][2 * H + e]);
+    }
+    if constexpr (SCALAR) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) v[e] = v[e] * gelu_erf(gt[e]);
+    } else
+    v = v * gelu_erf2(gt);
+    if constexpr (H == 0) {
+      o_lo[0] = from_f32<T>(v[0]); o_lo[1] = from_f32<T>(v[1]);
+    } else {
+      vec<T, 4> o;
+      o[0] = o_lo[0]; o[1] = o_lo[1]; o[2] = from_f32<T>(v[0]); o[3] = from_f32<T>(v[1]);
+      const int c = P * 4 + g;
+      const int row = rb * 32 + lq;
+      *reinterpret_cast<vec<T, 4>*>(stg + row * 128 + ((c ^ (row & 7)) << 4) + h2 * 8) = o;
+    }
   };
   constexpr int NU = GEGLU ? 8 : 16;   // units per tile
   // flush piece i of 8: 8 rows x 128 B leave the staging block as whole lines (DS operations of a wave execute in order: the
@@ -180,6 +220,12 @@ gemm_astat_kernel(const GemmParams p) {
       for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) STAR_ACC(SL)[rb][cb] = mfma32<T>(wf[ks & 1][cb], af[rb][ks], STAR_ACC(SL)[rb][cb]);
+      if constexpr (DRAIN && ILVP == 1 && GEGLU != 0) {   // half a unit per step; the next unit's LDS operands are fetched behind the first half
+        if constexpr (ks / 2 < NU) {
+          epi_half(std::integral_constant<int, SL ^ 1>{}, std::integral_constant<int, ks / 2>{}, std::integral_constant<int, ks % 2>{});
+          if constexpr (ks % 2 == 0 && ks / 2 + 1 < NU) epi_load(t - 1, std::integral_constant<int, ks / 2 + 1>{});
+        }
+      } else
       if constexpr (DRAIN) {   // one epilogue unit per step (GEGLU: per two steps); its LDS operands were fetched two steps earlier
         constexpr int STRIDE = GEGLU ? 2 : 1, LEAD = 2 / STRIDE;
         if constexpr (ks % STRIDE == 0 && ks / STRIDE < NU) {
@@ -193,7 +239,20 @@ gemm_astat_kernel(const GemmParams p) {
         if constexpr (ks >= 16) { flush_read(2 * (ks - 16), 0); flush_read(2 * (ks - 16) + 1, 1); }
         if constexpr (ks == KS - 1) wave_lds_order();   // ... and it is read out before the next tile's units overwrite it
       }
-      STAR_SCHED_FENCE();
+      // ILV 1: this step's 4 MFMAs, each followed by a quarter of its VALU.  ILV 2 (GEGLU): whole units as in ILV 0, but the fence
+      // between the unit's step and the next one is dropped and the pair's 8 MFMAs are each followed by an eighth of the unit
+      // (two independent polynomial chains side by side: no s_nop between dependent v_pk_fma_f32)
+      constexpr bool PAIR = ILVP == 2 && GEGLU != 0;
+      if constexpr (DRAIN && ILVP != 0 && !PAIR && ks < (GEGLU ? 2 * NU : NU)) {
+        constexpr int VPER = GEGLU ? (SCALAR ? 12 : 10) : (ILVP == 2 ? 4 : 6);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { STAR_SCHED_GROUP(0x008, 1, 0); STAR_SCHED_GROUP(0x002, VPER, 0); }
+      }
+      if constexpr (DRAIN && PAIR && ks % 2 == 1 && ks / 2 < NU) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { STAR_SCHED_GROUP(0x008, 1, 0); STAR_SCHED_GROUP(0x002, SCALAR ? 12 : 10, 0); }
+      }
+      if constexpr (!(DRAIN && PAIR && ks % 2 == 0 && ks / 2 < NU && ks + 1 < KS)) STAR_SCHED_FENCE();
     });
     if constexpr (FLUSH) { flush_store(t - 1, 6, 0, true); flush_store(t - 1, 7, 1, true); }
   };

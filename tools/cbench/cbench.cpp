@@ -103,6 +103,13 @@ static void* rand16(size_t n, float scale) {
   for (size_t off = 0; off < n; off += blk) upload(d + off * 2, h.data(), ((n - off < blk) ? n - off : blk) * 2);
   return d;
 }
+static void download(void* h, const void* d, size_t n) {
+#ifdef CBENCH_EMU
+  memcpy(h, d, n);
+#else
+  HCHECK(hipMemcpy(h, d, n, hipMemcpyDeviceToHost));
+#endif
+}
 static float* rand32(size_t n, float scale, float shift = 0.f) {
   std::vector<float> h(n);
   for (size_t i = 0; i < n; ++i) h[i] = nrand() * scale + shift;
@@ -240,10 +247,30 @@ int main(int argc, char** argv) {
       d.A = A; d.W = W; d.C = C; d.res = R; d.bias = (epi & STAR_EPI_BIAS) ? bias : nullptr;
       d.M = (int)M; d.N = (int)N; d.K = (int)K; d.ldc = (int)n_out; d.ldr = (int)n_out; d.epi = epi;
       d.rowab = rowab; d.colsum = (epi & STAR_EPI_ROWAFF) ? colsum : nullptr;
-      for (int tile : tiles) {
+      // every tile after the first is also compared bit for bit with the first one's output (hardware check of a variant against
+      // the kernel it would replace)
+      std::vector<uint16_t> first, cur;
+      for (size_t ti = 0; ti < tiles.size(); ++ti) {
+        const int tile = tiles[ti];
         d.force_tile = tile;
         snprintf(label, sizeof label, "%s tile=%d", stem, tile);
         T.run(label, 2.0 * M * N * K, reps, [&] { return api.gemm(ctx, &d); });
+        if (tiles.size() > 1) {
+          std::vector<uint16_t>& dst = ti == 0 ? first : cur;
+          dst.resize((size_t)M * n_out);
+          api.sync(ctx);
+          download(dst.data(), C, dst.size() * 2);
+          if (ti > 0) {
+            size_t bad = 0;
+            for (size_t i = 0; i < cur.size(); ++i) bad += cur[i] != first[i];
+            printf("    tile %d vs tile %d: %zu of %zu outputs differ%s\n", tile, tiles[0], bad, cur.size(), bad ? "" : " (bit-identical)");
+          }
+#ifndef CBENCH_EMU
+          HCHECK(hipMemset(C, 0xFF, (size_t)M * n_out * 2));     // the next tile must write every output itself
+#else
+          memset(C, 0xFF, (size_t)M * n_out * 2);
+#endif
+        }
       }
       dev_free(A); dev_free(W); dev_free(C); if (R) dev_free(R); dev_free(bias); dev_free(colsum); if (rowab) dev_free(rowab);
     } else if (kind == "attn") {
