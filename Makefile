@@ -52,7 +52,9 @@ tools/bench/libstar_hip_bench.so: $(BENCH_OBJS)
 	$(HIPCC) --offload-arch=gfx950 -shared -fPIC $^ -o $@
 
 # torch-free timing harness over the C ABI (dlopen()s a build of the library): seconds instead of minutes per A/B on a fresh GPU box
-cbench: tools/cbench/cbench tools/cbench/cbench_emu
+cbench: tools/cbench/cbench tools/cbench/cbench_emu tools/probe/mfma_valu_overlap
+tools/probe/mfma_valu_overlap: tools/probe/mfma_valu_overlap.hip
+	$(HIPCC) -O2 --offload-arch=gfx950 $< -o $@
 tools/cbench/cbench: tools/cbench/cbench.cpp include/star_hip.h
 	$(HIPCC) -O2 --offload-arch=gfx950 $< -o $@ -ldl
 tools/cbench/cbench_emu: tools/cbench/cbench.cpp include/star_hip.h
