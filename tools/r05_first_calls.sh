@@ -1,0 +1,24 @@
+#!/bin/bash
+# Round-5 opening measurements: each block is ONE gpurun call of well under a minute of run time; run from the
+# repo root on the GPU box (gpurun -- 'bash tools/r05_first_calls.sh 1').  Outputs under gpurun_out/ (copy what is quoted into profiles/).
+set -u
+mkdir -p gpurun_out
+case "${1:-1}" in
+  1)  # MFMA shadow: the other instruction kinds of the K / key loops, and two waves per SIMD
+      timeout 60 ./tools/probe/mfma_valu_overlap 20000 1 > gpurun_out/r05_probe_mfma_valu_overlap2.txt 2>&1
+      tail -5 gpurun_out/r05_probe_mfma_valu_overlap2.txt ;;
+  2)  # what the A-stationary kernel waits for: PMC passes on a torch-free run (counters in their own runs, kernel trace only)
+      cd /tmp && export TMPDIR=/tmp
+      R=${GRAFT_REPO_ROOT:-/root/repo}
+      printf 'gemm 843264 2560 320 37 30\ngemm 843264 960 320 33 30\n' > /tmp/astat.txt
+      for pmc in "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES" "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_WAVE_CYCLES" \
+                 "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES"; do
+        tag=$(echo "$pmc" | cut -d' ' -f1)
+        timeout 120 rocprofv3 --kernel-trace --pmc $pmc -d $R/gpurun_out/r05_pmc_astat_$tag -- \
+          $R/tools/cbench/cbench $R/tools/bench/libstar_hip_bench.so f16 /tmp/astat.txt 2 > $R/gpurun_out/r05_pmc_astat_$tag.log 2>&1
+      done
+      ls $R/gpurun_out | tail ;;
+  3)  # the tile sweep on the current tree (21 s)
+      timeout 90 ./tools/cbench/cbench tools/bench/libstar_hip_bench.so f16 tools/cbench/cfg2_tile_sweep.txt 6 > gpurun_out/r05_cbench_tile_sweep.txt 2>&1
+      tail -5 gpurun_out/r05_cbench_tile_sweep.txt ;;
+esac
