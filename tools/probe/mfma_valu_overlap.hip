@@ -16,7 +16,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <int FORM> __device__ __forceinline__ void mfma(f32x16& acc, f16x8 a, f16x8 b) {
   if constexpr (FORM == 0) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
-  else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+  else if constexpr (FORM == 1) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+  else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b));   // FORM 2: gemm_as.h's form -- B operand (the A panel) from an AGPR, accumulator in VGPRs
 }
 // KIND: 0 v_fma_f32, 1 v_pk_fma_f32, 2 v_exp_f32, 3 v_pk_add_f16, 4 v_pk_mul_f32, 5 v_cvt_pk_f16_f32 (e64), 6 v_max3_f32, 7 ds_read_b128
 // (LDS), 8 v_accvgpr_read_b32, 9 v_permlane32_swap
@@ -35,7 +36,11 @@ template <int KIND> __device__ __forceinline__ void valu(float& x, f32x2& p, flo
     asm volatile("" :: "v"(r));
   }
   else if constexpr (KIND == 8) { float s0 = spare[0]; asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(s0)); }
-  else asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(p[0]));
+  else if constexpr (KIND == 9) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(p[0]));
+  else {   // KIND 10: the epilogue's read pattern -- v_fma_f32 whose operand is an element of ANOTHER (idle) 16-register accumulator block in VGPRs
+    float s0 = spare[3];
+    asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(x) : "v"(s0), "v"(y));
+  }
 }
 
 template <int FORM, int KIND, int NV, int NT = 256>   // NT = 512: two waves per SIMD (does wave B's VALU overlap wave A's MFMA?)
@@ -128,6 +133,10 @@ int main(int argc, char** argv) {
   sweep<0, 0, 512>(out, iters, 1, "two waves per SIMD, v_fma_f32");
   sweep<0, 1, 512>(out, iters, 1, "two waves per SIMD, v_pk_fma_f32");
   sweep<0, 2, 512>(out, iters, 1, "two waves per SIMD, v_exp_f32");
+  // gemm_as.h's operand forms: B operand from an AGPR, accumulators in VGPRs; the epilogue's reads of an idle accumulator block
+  sweep<2, 0>(out, iters, 1, "B operand from AGPR + accumulators in VGPRs, v_fma_f32");
+  sweep<1, 10>(out, iters, 1, "accumulators in VGPRs, v_fma_f32 reading an idle accumulator block");
+  sweep<2, 10>(out, iters, 1, "B operand from AGPR + accumulators in VGPRs, v_fma_f32 reading an idle accumulator block");
   sweep<0, 3, 512>(out, iters, 1, "two waves per SIMD, v_pk_add_f16");
   return 0;
 }
