@@ -186,10 +186,8 @@ flash_attn_v3_kernel(const AttnParams p) {
               if (qi < q_lo || qi >= q_hi) continue;
               s[qi][kb] = mfma32<T>(kfa[ks][kb], qf[qi][ks], s[qi][kb]);
             }
-#ifndef STAR_HOSTEMU
         STAR_SCHED_GROUP(0x100, 8, 0);     // the eight ds_read_b128 first ...
         STAR_SCHED_GROUP(0x008, 20, 0);    // ... then the MFMAs back to back
-#endif
       } else {
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
@@ -346,14 +344,12 @@ flash_attn_v3_kernel(const AttnParams p) {
 #pragma unroll
       for (int qi = 0; qi < NQ; ++qi) { expo(qi); l_run[qi] += lsum[qi]; }
       pv(0, NQ);
-#ifndef STAR_HOSTEMU
       // interleave: the first 8 PV MFMAs (they only need P0) beside the VALU of expo(1)
       if constexpr (NQ == 2) for (int i = 0; i < 8; ++i) {
         STAR_SCHED_GROUP(0x008, 1, 0);   // 1 MFMA
         STAR_SCHED_GROUP(0x100, 2, 0);   // 2 DS reads
         STAR_SCHED_GROUP(0x002, 12, 0);  // 12 VALU
       }
-#endif
     } else if constexpr (LAZY == 1) {
       scores(0, NQ);
       if (t == 0) { maxima(0, NQ); rebase(0, NQ); }
@@ -437,7 +433,6 @@ flash_attn_v3_kernel(const AttnParams p) {
         expo_c(qi, 1);
       };
       auto hints = [&](auto n_ds, auto n_mfma, auto n_valu) {   // integral_constant arguments: the builtin wants literals
-#ifndef STAR_HOSTEMU
         if constexpr (HINTS) {
           if constexpr (decltype(n_ds)::value > 0) STAR_SCHED_GROUP(0x100, decltype(n_ds)::value, 0);
 #pragma unroll
@@ -446,7 +441,6 @@ flash_attn_v3_kernel(const AttnParams p) {
             STAR_SCHED_GROUP(0x002, decltype(n_valu)::value, 0);
           }
         }
-#endif
       };
       if constexpr (FIRST) {              // the first tile sets the running max from exact maxima
         scores(0, NQ);
@@ -572,7 +566,7 @@ flash_attn_v3_kernel(const AttnParams p) {
         scores_kb(0);
         scores_kb(1);
         expo_kb(0);
-#if !defined(STAR_HOSTEMU) && defined(STAR_ATTN_V8_HINTS)
+#ifdef STAR_ATTN_V8_HINTS
         for (int i = 0; i < 10; ++i) {      // QK of half 1 beside the exponentials of half 0
           STAR_SCHED_GROUP(0x008, 1, 0);    // 1 MFMA
           STAR_SCHED_GROUP(0x002, 8, 0);    // 8 VALU
@@ -583,7 +577,7 @@ flash_attn_v3_kernel(const AttnParams p) {
         for (int qi = 0; qi < NQ; ++qi) l_run[qi] += lk[qi];
         pv_kb(0);
         expo_kb(1);
-#if !defined(STAR_HOSTEMU) && defined(STAR_ATTN_V8_HINTS)
+#ifdef STAR_ATTN_V8_HINTS
         for (int i = 0; i < 8; ++i) {       // PV of half 0 beside the exponentials of half 1
           STAR_SCHED_GROUP(0x008, 1, 0);
           STAR_SCHED_GROUP(0x002, 10, 0);
@@ -609,13 +603,11 @@ flash_attn_v3_kernel(const AttnParams p) {
         l_run[qi] += lsum[qi];
         pv(qi, qi + 1);                    // PV of this block ...
         if (qi + 1 < NQ) expo(qi + 1);     // ... beside the exponentials of the next one
-#ifndef STAR_HOSTEMU
         if (qi + 1 < NQ) for (int i = 0; i < 8; ++i) {
           STAR_SCHED_GROUP(0x008, 1, 0);   // 1 MFMA
           STAR_SCHED_GROUP(0x100, 2, 0);   // 2 DS reads
           STAR_SCHED_GROUP(0x002, 12, 0);  // 12 VALU
         }
-#endif
       }
     }
   };

@@ -22,19 +22,6 @@
 
 namespace star {
 
-// packed 16-bit add (v_pk_add_f16); the emulator rounds each lane's sum to T exactly like the instruction does
-template <class T>
-STAR_DEV vec<T, 2> pk_add(vec<T, 2> a, vec<T, 2> b) {
-#ifdef STAR_HOSTEMU
-  vec<T, 2> r;
-  r[0] = from_f32<T>(to_f32<T>(a[0]) + to_f32<T>(b[0]));
-  r[1] = from_f32<T>(to_f32<T>(a[1]) + to_f32<T>(b[1]));
-  return r;
-#else
-  return a + b;
-#endif
-}
-
 // CAUSAL = 1 (text tower, embedder.py:59: open_clip's attn_mask): key j is visible to query i only for j <= i; Nq == Nk, the mask
 // is applied to the scores of every tile (and again on the recompute path), so masked probabilities are exact zeros.
 template <class T, int PKSUM, int AUGK8 = 0, int CAUSAL = 0>   // AUGK8: the augmented k-step as a half-depth 32x32x8 MFMA (one useful k of 8 instead of 16: +1-4 %, bit-identical; shipped)

@@ -573,6 +573,18 @@ STAR_DEV uint64_t wave_ballot(bool pred) {
   return m;
 #endif
 }
+// packed 16-bit add (v_pk_add_f16; attn5.h's row sums); the emulator rounds each lane's sum to T exactly like the instruction does
+template <class T>
+STAR_DEV vec<T, 2> pk_add(vec<T, 2> a, vec<T, 2> b) {
+#ifdef STAR_HOSTEMU
+  vec<T, 2> r;
+  r[0] = from_f32<T>(to_f32<T>(a[0]) + to_f32<T>(b[0]));
+  r[1] = from_f32<T>(to_f32<T>(a[1]) + to_f32<T>(b[1]));
+  return r;
+#else
+  return a + b;
+#endif
+}
 // compile-time scheduling hint (LLVM sched_group_barrier): emit `n` instructions of class `mask` next
 #ifdef STAR_HOSTEMU
 #define STAR_SCHED_GROUP(mask, n, id)
