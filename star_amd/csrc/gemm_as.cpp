@@ -27,6 +27,10 @@ static int launch_astat(Ctx* ctx, const GemmArgs& a) {
   if (a.force_tile == 33) { STAR_LAUNCH((gemm_astat_kernel<T, 0, 3>), grid, block, smem, ctx->stream, p); return 0; }
   if (a.force_tile == 34) { STAR_LAUNCH((gemm_astat_kernel<T, 0, 4>), grid, block, smem, ctx->stream, p); return 0; }
   if (a.force_tile == 35) { STAR_LAUNCH((gemm_astat_kernel<T, 0, 5>), grid, block, smem, ctx->stream, p); return 0; }
+  if (a.force_tile == 41) {   // no global stores (timing only): are the flush's stores what the per-tile vmcnt wait waits for?
+    if (a.epi & EPI_GEGLU) STAR_LAUNCH((gemm_astat_kernel<T, 1, 6>), grid, block, smem, ctx->stream, p); else STAR_LAUNCH((gemm_astat_kernel<T, 0, 6>), grid, block, smem, ctx->stream, p);
+    return 0;
+  }
   // scheduling variants (correct results, bit-identical): 36 / 37 = ILV 1 / 2 (sched_group_barrier interleave of the epilogue with the
   // MFMAs: half units per step / whole units over a pair of steps), 38 / 39 / 40 = the same placements 1 / 0 / 2 with the GELU
   // polynomial as scalar v_fma_f32 (which overlap a wave's own MFMAs; v_pk_fma_f32 do not)

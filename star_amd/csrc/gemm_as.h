@@ -20,15 +20,20 @@
 
 namespace star {
 
+// ABL 6 (round 4, for round 5's first call): everything but the GLOBAL STORES of the flush (the epilogue's VALU, the staging writes and
+// the flush reads stay) -- vmcnt retires in order, so the per-tile wait for the next W tile's LDS-DMA also waits for the OLDER stores of
+// the flush before it: if the store latency under load exceeds a tile time, that wait is the epilogue's unexplained 0.22 ms.
 // ABL (bench builds, timing only, wrong results): 1 no epilogue, 2 no W staging / barrier after tile 0, 3 W fragments not re-read,
 // 4 = 1 + 2 (the k loop alone: MFMAs + W fragment reads), 5 = 4 + 3 (MFMAs alone)
 // ILV: the epilogue pieces are INTERLEAVED with the MFMAs of a k-step by sched_group_barrier patterns (1 MFMA, then a share of the
 // step's VALU) instead of being left to the scheduler, which clusters them (ISA of the ILV = 0 GEGLU loop: 8 MFMAs back to back, then
 // ~75 VALU with the matrix pipe idle -- 560 cycles per two k-steps where max(MFMA, VALU) is 380); GEGLU units are split in two halves
 // (one per k-step) so that every step carries VALU work.  Same instructions, same arithmetic: bit-identical.
-template <class T, int GEGLU, int ABL = 0, int ILV = 0>
+template <class T, int GEGLU, int ABL_ = 0, int ILV = 0>
 STAR_GLOBAL void STAR_LAUNCH_BOUNDS(256, 1)
 gemm_astat_kernel(const GemmParams p) {
+  constexpr int ABL = ABL_ >= 6 ? 0 : ABL_;     // 6: the product paths everywhere except the global stores
+  constexpr bool NOSTORE = ABL_ == 6;
   constexpr int K = 320, KS = K / 16, SLAB = 64 * 128, WTILE = (K / 64) * SLAB;   // 40 KB per 64-row W tile
   constexpr int STG = 64 * 128;                 // per-wave staging block: 64 rows x 64 outputs (GEGLU: two W tiles fill it)
   char* smem = dyn_smem();
@@ -175,7 +180,8 @@ gemm_astat_kernel(const GemmParams p) {
   auto flush_store = [&](int tp, int i, int slot, bool live_all) STAR_ALWAYS_INLINE {
     const uint32_t col0 = (uint32_t)(GEGLU ? (tp >> 1) * 64 : tp * 64) * 2u;
     const bool live = live_all || (lane & 7) < 4;   // an odd GEGLU tile count leaves the upper half of the block stale
-    buf_store16(crs, live ? srow_g + i * srow_step + col0 : GLDS_BUF_OOB, fl[slot]);
+    if constexpr (NOSTORE) { asm volatile("" :: "v"(fl[slot])); (void)live; (void)col0; }
+    else buf_store16(crs, live ? srow_g + i * srow_step + col0 : GLDS_BUF_OOB, fl[slot]);
   };
 
   auto tile = [&](int t, auto slot_tag, auto drain_tag) STAR_ALWAYS_INLINE {
@@ -186,7 +192,7 @@ gemm_astat_kernel(const GemmParams p) {
     // W tile t has landed (the only vector-memory operations issued after its DMA are the 8 stores of the previous tile's
     // flush, if it had one; vmcnt retires in order), and every wave is done reading the other slot
     if ((ABL != 2 && ABL < 4) || t == 0) {
-      if (prev_flushed && ABL != 1 && ABL < 4) STAR_WAIT_VMCNT_N(8); else STAR_WAIT_VMCNT(0);
+      if (prev_flushed && ABL != 1 && ABL < 4 && !NOSTORE) STAR_WAIT_VMCNT_N(8); else STAR_WAIT_VMCNT(0);
       barrier_keep_dma();
       if (t + 1 < nt && ABL != 2 && ABL < 4) stage(t + 1, SL ^ 1);
     }

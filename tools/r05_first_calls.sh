@@ -18,6 +18,9 @@ case "${1:-1}" in
           $R/tools/cbench/cbench $R/tools/bench/libstar_hip_bench.so f16 /tmp/astat.txt 2 > $R/gpurun_out/r05_pmc_astat_$tag.log 2>&1
       done
       ls $R/gpurun_out | tail ;;
+  4)  # A-stationary kernel without its global stores (hypothesis: in-order vmcnt couples the W-tile wait to the stores' latency)
+      timeout 60 ./tools/cbench/cbench tools/bench/libstar_hip_bench.so f16 tools/cbench/astat_nostore.txt 8 > gpurun_out/r05_cbench_astat_nostore.txt 2>&1
+      cat gpurun_out/r05_cbench_astat_nostore.txt ;;
   3)  # the tile sweep on the current tree (21 s)
       timeout 90 ./tools/cbench/cbench tools/bench/libstar_hip_bench.so f16 tools/cbench/cfg2_tile_sweep.txt 6 > gpurun_out/r05_cbench_tile_sweep.txt 2>&1
       tail -5 gpurun_out/r05_cbench_tile_sweep.txt ;;
