@@ -27,6 +27,10 @@ static int launch_astat(Ctx* ctx, const GemmArgs& a) {
   if (a.force_tile == 33) { STAR_LAUNCH((gemm_astat_kernel<T, 0, 3>), grid, block, smem, ctx->stream, p); return 0; }
   if (a.force_tile == 34) { STAR_LAUNCH((gemm_astat_kernel<T, 0, 4>), grid, block, smem, ctx->stream, p); return 0; }
   if (a.force_tile == 35) { STAR_LAUNCH((gemm_astat_kernel<T, 0, 5>), grid, block, smem, ctx->stream, p); return 0; }
+  if (a.force_tile == 42) {   // ILV 6: the two row blocks of a column quad share one fetch of its column sums / biases (correct results, bit-identical)
+    if (a.epi & EPI_GEGLU) STAR_LAUNCH((gemm_astat_kernel<T, 1, 0, 6>), grid, block, smem, ctx->stream, p); else STAR_LAUNCH((gemm_astat_kernel<T, 0, 0, 6>), grid, block, smem, ctx->stream, p);
+    return 0;
+  }
   if (a.force_tile == 41) {   // no global stores (timing only): are the flush's stores what the per-tile vmcnt wait waits for?
     if (a.epi & EPI_GEGLU) STAR_LAUNCH((gemm_astat_kernel<T, 1, 6>), grid, block, smem, ctx->stream, p); else STAR_LAUNCH((gemm_astat_kernel<T, 0, 6>), grid, block, smem, ctx->stream, p);
     return 0;

@@ -43,8 +43,13 @@ gemm_astat_kernel(const GemmParams p) {
   // profiles/r04_probe_mfma_valu_overlap.txt): a wave's v_fma_f32 ride in the shadow of its own MFMAs (4 per MFMA for free, 4.3
   // cycles each beyond), its v_pk_fma_f32 do NOT (MFMA + 16 + 4.4 cycles each, no overlap at all) -- packed fp32 only pays where no
   // MFMA is in flight.  ILV 3 = 1 + scalar, 4 = 0 + scalar, 5 = 2 + scalar.
-  constexpr bool SCALAR = ILV >= 3;
-  constexpr int ILVP = ILV >= 3 ? (ILV == 3 ? 1 : ILV == 4 ? 0 : 2) : ILV;   // the placement pattern
+  // ILV 6: the product placement with the units re-ordered so that the two row blocks of a column quad are CONSECUTIVE and share one
+  // fetch of its column sums / biases: 16 instead of 32 ds_read_b128 per tile and wave.  (Per W tile a CU's LDS moves 160 KB of W
+  // fragments + 128 KB of these broadcast reads + 40 KB of staging and flush + the 40 KB DMA fill: ~2900 cycles at 128 B/clk against
+  // 2560 cycles of MFMA -- the epilogue may be LDS-bandwidth-bound rather than issue-bound.)
+  constexpr bool SCALAR = ILV >= 3 && ILV <= 5;
+  constexpr bool SHARE = ILV == 6;
+  constexpr int ILVP = ILV == 6 ? 0 : ILV >= 3 ? (ILV == 3 ? 1 : ILV == 4 ? 0 : 2) : ILV;   // the placement pattern
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = wave_uniform(tid >> 6);
   const int h2 = lane >> 5, lq = lane & 31;
@@ -116,22 +121,24 @@ gemm_astat_kernel(const GemmParams p) {
                                           // step ahead the compiler's wait for them also drained the W fragment reads, 20 times per tile)
   auto epi_load = [&](int tp, auto utag) STAR_ALWAYS_INLINE {
     constexpr int U = decltype(utag)::value;
-    constexpr int cb = GEGLU ? 0 : (U / 4) % 2, g = U % 4;
+    constexpr int Q = SHARE ? U / 2 : U;                      // SHARE: unit U = (column quad U / 2, row block U % 2)
+    constexpr int cb = GEGLU ? 0 : (Q / 4) % 2, g = Q % 4, S = Q & 1;
     const float* bl = bias_lds + tp * 64;
     const int nl = cb * 32 + 8 * g + 4 * h2;
-    ecs[U & 1] = *reinterpret_cast<const f32x4*>(bl + N + nl); ecb[U & 1] = *reinterpret_cast<const f32x4*>(bl + nl);
-    if constexpr (GEGLU != 0) { egs[U & 1] = *reinterpret_cast<const f32x4*>(bl + N + nl + 32); egb[U & 1] = *reinterpret_cast<const f32x4*>(bl + nl + 32); }
+    ecs[S] = *reinterpret_cast<const f32x4*>(bl + N + nl); ecb[S] = *reinterpret_cast<const f32x4*>(bl + nl);
+    if constexpr (GEGLU != 0) { egs[S] = *reinterpret_cast<const f32x4*>(bl + N + nl + 32); egb[S] = *reinterpret_cast<const f32x4*>(bl + nl + 32); }
   };
   auto epi_unit = [&](auto ptag, auto utag) STAR_ALWAYS_INLINE {   // drains accumulator set P with the operands epi_load fetched
     constexpr int P = decltype(ptag)::value, U = decltype(utag)::value;
-    constexpr int rb = U / (GEGLU ? 4 : 8), cb = GEGLU ? 0 : (U / 4) % 2, g = U % 4;
+    constexpr int Q = SHARE ? U / 2 : U, S = Q & 1;
+    constexpr int rb = SHARE ? U % 2 : U / (GEGLU ? 4 : 8), cb = GEGLU ? 0 : (Q / 4) % 2, g = Q % 4;
     f32x4 v;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = ra[rb] * STAR_ACC(P)[rb][cb][g * 4 + e] + (rbv[rb] * ecs[U & 1][e] + ecb[U & 1][e]);
+    for (int e = 0; e < 4; ++e) v[e] = ra[rb] * STAR_ACC(P)[rb][cb][g * 4 + e] + (rbv[rb] * ecs[S][e] + ecb[S][e]);
     if constexpr (GEGLU != 0) {
       f32x4 gt;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) gt[e] = ra[rb] * STAR_ACC(P)[rb][1][g * 4 + e] + (rbv[rb] * egs[U & 1][e] + egb[U & 1][e]);
+      for (int e = 0; e < 4; ++e) gt[e] = ra[rb] * STAR_ACC(P)[rb][1][g * 4 + e] + (rbv[rb] * egs[S][e] + egb[S][e]);
       if constexpr (SCALAR) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = v[e] * gelu_erf(gt[e]);
@@ -213,7 +220,7 @@ gemm_astat_kernel(const GemmParams p) {
     for (int cb = 0; cb < 2; ++cb) wf[0][cb] = *reinterpret_cast<const vec<T, 8>*>(wfa[SL][0] + cb * 4096);
     if constexpr (DRAIN) {
       epi_load(t - 1, std::integral_constant<int, 0>{});
-      if constexpr (GEGLU == 0) epi_load(t - 1, std::integral_constant<int, 1>{});
+      if constexpr (GEGLU == 0 && !SHARE) epi_load(t - 1, std::integral_constant<int, 1>{});
     }
     static_for<KS>([&](auto kstag) STAR_ALWAYS_INLINE {
       constexpr int ks = decltype(kstag)::value;
@@ -236,6 +243,9 @@ gemm_astat_kernel(const GemmParams p) {
         constexpr int STRIDE = GEGLU ? 2 : 1, LEAD = 2 / STRIDE;
         if constexpr (ks % STRIDE == 0 && ks / STRIDE < NU) {
           epi_unit(std::integral_constant<int, SL ^ 1>{}, std::integral_constant<int, ks / STRIDE>{});
+          if constexpr (SHARE) {   // behind the first unit of a pair: the next pair's operands (the other slot)
+            if constexpr ((ks / STRIDE) % 2 == 0 && ks / STRIDE + 2 < NU) epi_load(t - 1, std::integral_constant<int, ks / STRIDE + 2>{});
+          } else
           if constexpr (ks / STRIDE + LEAD < NU) epi_load(t - 1, std::integral_constant<int, ks / STRIDE + LEAD>{});
         }
       }
@@ -275,7 +285,7 @@ gemm_astat_kernel(const GemmParams p) {
   // ---- drain the last tile (its accumulators sit in set (nt - 1) & 1)
   if constexpr (ABL != 1 && ABL < 4) {
     static_for<NU>([&](auto u) STAR_ALWAYS_INLINE {
-      epi_load(nt - 1, u);
+      if constexpr (!SHARE || decltype(u)::value % 2 == 0) epi_load(nt - 1, u);
       if ((nt - 1) & 1) epi_unit(std::integral_constant<int, 1>{}, u); else epi_unit(std::integral_constant<int, 0>{}, u);
     });
     wave_lds_order();
