@@ -45,8 +45,8 @@ gemm_astat_kernel(const GemmParams p) {
   // MFMA is in flight.  ILV 3 = 1 + scalar, 4 = 0 + scalar, 5 = 2 + scalar.
   // ILV 6: the product placement with the units re-ordered so that the two row blocks of a column quad are CONSECUTIVE and share one
   // fetch of its column sums / biases: 16 instead of 32 ds_read_b128 per tile and wave.  (Per W tile a CU's LDS moves 160 KB of W
-  // fragments + 128 KB of these broadcast reads + 40 KB of staging and flush + the 40 KB DMA fill: ~2900 cycles at 128 B/clk against
-  // 2560 cycles of MFMA -- the epilogue may be LDS-bandwidth-bound rather than issue-bound.)
+  // fragments + 128 KB of these broadcast reads + 40 KB of staging and flush + the 40 KB DMA fill: ~2100 LDS-array cycles against 2560
+  // cycles of MFMA -- the W fragment reads the MFMAs wait for queue behind the epilogue's.)
   constexpr bool SCALAR = ILV >= 3 && ILV <= 5;
   constexpr bool SHARE = ILV == 6;
   constexpr int ILVP = ILV == 6 ? 0 : ILV >= 3 ? (ILV == 3 ? 1 : ILV == 4 ? 0 : 2) : ILV;   // the placement pattern
