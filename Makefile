@@ -21,14 +21,19 @@ build/hip/attn.o: HIPFLAGS += -fno-honor-nans -fno-slp-vectorize
 build/hip/attn7.o: HIPFLAGS += -fno-honor-nans -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form
 build/hip/gemm_as.o: HIPFLAGS += -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form
 build/hip/gemm_tq.o: HIPFLAGS += -fno-honor-nans -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form
-# precise header dependencies (-MMD): touching norm.h no longer recompiles the GEMM instantiation units (minutes each)
-build/hip/%.o: $(CSRC)/%.cpp
+# precise header dependencies (-MMD): touching norm.h no longer recompiles the GEMM instantiation units (minutes each).
+# An object WITHOUT its .d file (a build tree from before -MMD, or a .d deleted by hand) has unknown header dependencies: it
+# depends on every header until its .d exists again (secondary expansion: the prerequisite list is computed per target), so a
+# struct layout change in ctx.h / gemm.h can never be linked against a stale object.
+HDRS := $(wildcard $(CSRC)/*.h $(CSRC)/*.inc) include/star_hip.h
+.SECONDEXPANSION:
+build/hip/%.o: $(CSRC)/%.cpp $$(if $$(wildcard build/hip/$$*.d),,$$(HDRS))
 	@mkdir -p build/hip
 	$(HIPCC) $(HIPFLAGS) -MMD -MP -c $< -o $@
 star_amd/libstar_hip.so: $(HIP_OBJS)
 	$(HIPCC) --offload-arch=gfx950 -shared -fPIC $^ -o $@
 
-build/emu/%.o: $(CSRC)/%.cpp
+build/emu/%.o: $(CSRC)/%.cpp $$(if $$(wildcard build/emu/$$*.d),,$$(HDRS))
 	@mkdir -p build/emu
 	$(CLANGXX) $(EMUFLAGS) -MMD -MP -c $< -o $@
 build/emu/hostemu.o: tools/hostemu/hostemu.cpp $(CSRC)/hostemu.h
@@ -44,7 +49,7 @@ build/bench/attn.o: HIPFLAGS += -fno-honor-nans -fno-slp-vectorize
 build/bench/attn7.o: HIPFLAGS += -fno-honor-nans -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form
 build/bench/gemm_as.o: HIPFLAGS += -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form
 build/bench/gemm_tq.o: HIPFLAGS += -fno-honor-nans -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form
-build/bench/%.o: $(CSRC)/%.cpp
+build/bench/%.o: $(CSRC)/%.cpp $$(if $$(wildcard build/bench/$$*.d),,$$(HDRS))
 	@mkdir -p build/bench
 	$(HIPCC) $(HIPFLAGS) -DSTAR_BENCH_VARIANTS=1 -MMD -MP -c $< -o $@
 tools/bench/libstar_hip_bench.so: $(BENCH_OBJS)
@@ -58,7 +63,7 @@ tools/probe/mfma_valu_overlap: tools/probe/mfma_valu_overlap.hip
 tools/cbench/cbench: tools/cbench/cbench.cpp include/star_hip.h
 	$(HIPCC) -O2 --offload-arch=gfx950 $< -o $@ -ldl
 tools/cbench/cbench_emu: tools/cbench/cbench.cpp include/star_hip.h
-	g++ -O2 -DCBENCH_EMU $< -o $@ -ldl
+	$(CXX) -O2 -DCBENCH_EMU $< -o $@ -ldl
 
 -include $(wildcard build/hip/*.d build/emu/*.d build/bench/*.d)
 

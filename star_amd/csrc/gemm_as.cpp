@@ -35,6 +35,21 @@ static int launch_astat(Ctx* ctx, const GemmArgs& a) {
     if (a.epi & EPI_GEGLU) STAR_LAUNCH((gemm_astat_kernel<T, 1, 6>), grid, block, smem, ctx->stream, p); else STAR_LAUNCH((gemm_astat_kernel<T, 0, 6>), grid, block, smem, ctx->stream, p);
     return 0;
   }
+  if (a.force_tile >= 47 && a.force_tile <= 50) {   // round 5 (correct results): staggered first round, 1 / 2 / 4 / 8 sleep units (127 x 64 cycles) per phase
+    p.group_m = 1 << (a.force_tile - 47);
+    if (a.epi & EPI_GEGLU) STAR_LAUNCH((gemm_astat_kernel<T, 1, 11>), grid, block, smem, ctx->stream, p); else STAR_LAUNCH((gemm_astat_kernel<T, 0, 11>), grid, block, smem, ctx->stream, p);
+    return 0;
+  }
+  if (a.force_tile >= 43 && a.force_tile <= 46) {   // round 5 (correct results): 43 / 44 / 45 = the flush's stores non-temporal / write-through / both; 46 = every per-tile wait is vmcnt(0)
+    const bool g = (a.epi & EPI_GEGLU) != 0;
+    switch (a.force_tile) {
+      case 43: if (g) STAR_LAUNCH((gemm_astat_kernel<T, 1, 7>), grid, block, smem, ctx->stream, p); else STAR_LAUNCH((gemm_astat_kernel<T, 0, 7>), grid, block, smem, ctx->stream, p); break;
+      case 44: if (g) STAR_LAUNCH((gemm_astat_kernel<T, 1, 8>), grid, block, smem, ctx->stream, p); else STAR_LAUNCH((gemm_astat_kernel<T, 0, 8>), grid, block, smem, ctx->stream, p); break;
+      case 45: if (g) STAR_LAUNCH((gemm_astat_kernel<T, 1, 9>), grid, block, smem, ctx->stream, p); else STAR_LAUNCH((gemm_astat_kernel<T, 0, 9>), grid, block, smem, ctx->stream, p); break;
+      default: if (g) STAR_LAUNCH((gemm_astat_kernel<T, 1, 10>), grid, block, smem, ctx->stream, p); else STAR_LAUNCH((gemm_astat_kernel<T, 0, 10>), grid, block, smem, ctx->stream, p); break;
+    }
+    return 0;
+  }
   // scheduling variants (correct results, bit-identical): 36 / 37 = ILV 1 / 2 (sched_group_barrier interleave of the epilogue with the
   // MFMAs: half units per step / whole units over a pair of steps), 38 / 39 / 40 = the same placements 1 / 0 / 2 with the GELU
   // polynomial as scalar v_fma_f32 (which overlap a wave's own MFMAs; v_pk_fma_f32 do not)

@@ -34,6 +34,18 @@ STAR_GLOBAL void STAR_LAUNCH_BOUNDS(256, 1)
 gemm_astat_kernel(const GemmParams p) {
   constexpr int ABL = ABL_ >= 6 ? 0 : ABL_;     // 6: the product paths everywhere except the global stores
   constexpr bool NOSTORE = ABL_ == 6;
+  // 7 / 8 / 9 (round 5, correct results): the flush's stores with a cache policy -- non-temporal / write-through / both (prim.h:
+  // buf_store16_pol); 10: every per-tile wait drains ALL vector-memory operations (vmcnt(0): how much is the counted wait worth?)
+  constexpr int STPOL = ABL_ == 7 ? 2 : ABL_ == 8 ? 16 : ABL_ == 9 ? 19 : 0;
+  constexpr bool DRAIN_ALL = ABL_ == 10;
+  // 11 (round 5, correct results): the FIRST round of workgroups starts staggered.  Every workgroup does the same work, so all 256 CUs run
+  // in lockstep: their A-panel prologues (164 KB per CU, 42 MB at once) are one HBM burst during which nobody computes (~14 us of the
+  // ~33 us a workgroup lives at N = 960).  Phase p = (blockIdx / 8) % 8 of the first 256 workgroups sleeps p * group_m * 127 * 64 cycles;
+  // later workgroups inherit the phase of the one they replace.
+  constexpr bool STAGGER = ABL_ == 11;
+  if constexpr (STAGGER) {
+    if (blockIdx.x < 256) wave_sleep(((int)(blockIdx.x >> 3) & 7) * p.group_m * 127);
+  }
   constexpr int K = 320, KS = K / 16, SLAB = 64 * 128, WTILE = (K / 64) * SLAB;   // 40 KB per 64-row W tile
   constexpr int STG = 64 * 128;                 // per-wave staging block: 64 rows x 64 outputs (GEGLU: two W tiles fill it)
   char* smem = dyn_smem();
@@ -188,6 +200,7 @@ gemm_astat_kernel(const GemmParams p) {
     const uint32_t col0 = (uint32_t)(GEGLU ? (tp >> 1) * 64 : tp * 64) * 2u;
     const bool live = live_all || (lane & 7) < 4;   // an odd GEGLU tile count leaves the upper half of the block stale
     if constexpr (NOSTORE) { asm volatile("" :: "v"(fl[slot])); (void)live; (void)col0; }
+    else if constexpr (STPOL != 0) buf_store16_pol<STPOL>(crs, live ? srow_g + i * srow_step + col0 : GLDS_BUF_OOB, fl[slot]);
     else buf_store16(crs, live ? srow_g + i * srow_step + col0 : GLDS_BUF_OOB, fl[slot]);
   };
 
@@ -199,7 +212,7 @@ gemm_astat_kernel(const GemmParams p) {
     // W tile t has landed (the only vector-memory operations issued after its DMA are the 8 stores of the previous tile's
     // flush, if it had one; vmcnt retires in order), and every wave is done reading the other slot
     if ((ABL != 2 && ABL < 4) || t == 0) {
-      if (prev_flushed && ABL != 1 && ABL < 4 && !NOSTORE) STAR_WAIT_VMCNT_N(8); else STAR_WAIT_VMCNT(0);
+      if (prev_flushed && ABL != 1 && ABL < 4 && !NOSTORE && !DRAIN_ALL) STAR_WAIT_VMCNT_N(8); else STAR_WAIT_VMCNT(0);
       barrier_keep_dma();
       if (t + 1 < nt && ABL != 2 && ABL < 4) stage(t + 1, SL ^ 1);
     }

@@ -15,7 +15,7 @@ static inline unsigned ew_grid(long long total, int block = 256) {
 // ab_out != nullptr: statistics + finalize only -- the per-(stat, channel) affine pairs go to ab_out and nothing is applied
 template <class T>
 static int gn_t(Ctx* ctx, const void* x, int ldx, void* y, int ldy, const float* gamma, const float* beta,
-                int rows, int C, int rows_per_stat, float eps, bool silu, float* ab_out = nullptr) {
+                int rows, int C, int rows_per_stat, float eps, bool silu, float* ab_out = nullptr, float* mu_out = nullptr) {
   const int nstat = rows / rows_per_stat;
   const int CC8 = C / 8;
   int RL = 256 / CC8; if (RL < 1) RL = 1;
@@ -36,7 +36,7 @@ static int gn_t(Ctx* ctx, const void* x, int ldx, void* y, int ldy, const float*
   GnStatsParams sp{x, ldx, C, rows_per_stat, slab, partial.as<double>()};
   dim3 grid((unsigned)nslab, (unsigned)nstat);
   STAR_LAUNCH((gn_stats_kernel<T>), grid, dim3(nthreads), (size_t)nthreads * 64, ctx->stream, sp);
-  GnFinalizeParams fp{partial.as<double>(), gamma, beta, abp, C, nstat, nslab, count, eps};
+  GnFinalizeParams fp{partial.as<double>(), gamma, beta, abp, C, nstat, nslab, count, eps, mu_out};
   STAR_LAUNCH(gn_finalize_kernel, dim3((unsigned)((nstat * 32 + 3) / 4)), dim3(256), (size_t)0, ctx->stream, fp);
   if (ab_out) return 0;
   GnApplyParams ap{x, y, abp, ldx, ldy, C, rows_per_stat, slab, silu ? 1 : 0};
@@ -56,21 +56,21 @@ int op_group_norm(Ctx* ctx, const void* x, int ldx, void* y, int ldy, const floa
 }
 
 int op_group_norm_stats(Ctx* ctx, const void* x, int ldx, const float* gamma, const float* beta, int rows, int C, int rows_per_stat,
-                        float eps, float* ab) {
+                        float eps, float* ab, float* mu) {
   if (C % 32 || C % 8) return ctx->fail("group_norm: C must be a multiple of 32");
   if (rows % rows_per_stat) return ctx->fail("group_norm: rows not a multiple of rows_per_stat");
   if (ldx & 7) return ctx->fail("group_norm: row strides must be multiples of 8");
   if (C / 8 > 1024) return ctx->fail("group_norm: C too large");
   if (!ab) return ctx->fail("group_norm_stats: null output");
   ProfScope ps(ctx, PK_GN, 0.0, 1.0 * rows * (double)C * 2.0);
-  if (ctx->dtype == DT_F16) return gn_t<f16>(ctx, x, ldx, nullptr, 8, gamma, beta, rows, C, rows_per_stat, eps, false, ab);
-  return gn_t<bf16>(ctx, x, ldx, nullptr, 8, gamma, beta, rows, C, rows_per_stat, eps, false, ab);
+  if (ctx->dtype == DT_F16) return gn_t<f16>(ctx, x, ldx, nullptr, 8, gamma, beta, rows, C, rows_per_stat, eps, false, ab, mu);
+  return gn_t<bf16>(ctx, x, ldx, nullptr, 8, gamma, beta, rows, C, rows_per_stat, eps, false, ab, mu);
 }
 
-int op_gn_fold_weights(Ctx* ctx, const void* W, const float* bias, const float* ab, void* Wout, float* bias_out, int N, int K) {
+int op_gn_fold_weights(Ctx* ctx, const void* W, const float* bias, const float* ab, void* Wout, float* bias_out, int N, int K, const float* mu) {
   if (N <= 0 || K <= 0) return 0;
   ProfScope ps(ctx, PK_GN, 0.0, 2.0 * N * (double)K * 2.0);
-  GnFoldParams p{W, bias, ab, Wout, bias_out, N, K};
+  GnFoldParams p{W, bias, ab, Wout, bias_out, N, K, mu};
   if (ctx->dtype == DT_F16) STAR_LAUNCH((gn_fold_weights_kernel<f16>), dim3((unsigned)N), dim3(256), (size_t)256 * 4, ctx->stream, p);
   else STAR_LAUNCH((gn_fold_weights_kernel<bf16>), dim3((unsigned)N), dim3(256), (size_t)256 * 4, ctx->stream, p);
   return 0;

@@ -21,7 +21,7 @@ struct GnStatsParams {
 // partial sums of one (stat, group) -> the affine pairs of the group's channels: one wavefront, lanes stride over the slabs in
 // order, then a fixed shuffle tree (shared by the folded and the separate finalize: bit-identical results)
 STAR_DEV void gn_finalize_group(const double* partial, int nslab, int stat, int g, int C, double count, float eps, const float* gamma,
-                                const float* beta, float* ab, int lane) {
+                                const float* beta, float* ab, int lane, float* mu = nullptr) {
   double a = 0.0, b = 0.0;
   const double* q0 = partial + ((size_t)stat * 32 + g) * (size_t)nslab * 2;
   for (int sl = lane; sl < nslab; sl += 64) {
@@ -43,6 +43,7 @@ STAR_DEV void gn_finalize_group(const double* partial, int nslab, int stat, int 
     const float sc = gamma[c] * rstd;
     ab[2 * ((size_t)stat * C + c)] = sc;
     ab[2 * ((size_t)stat * C + c) + 1] = beta[c] - (float)mean * sc;
+    if (mu) mu[(size_t)stat * C + c] = (float)mean;   // the group mean per channel, for the weight fold (gn_fold_weights_kernel)
   }
 }
 // Deterministic by construction (fixed reduction order, no atomics): every launch gives bit-identical statistics, hence a
@@ -109,12 +110,13 @@ STAR_GLOBAL void gn_stats_kernel(const GnStatsParams p) {
 struct GnFinalizeParams {
   const double* partial; const float* gamma; const float* beta; float* ab;  // ab[nstat][C][2]
   int C; int nstat; int nslab; double count; float eps;
+  float* mu;   // optional [nstat][C]: the channel's group mean
 };
 STAR_GLOBAL void gn_finalize_kernel(const GnFinalizeParams p) {
   const int lane = threadIdx.x & 63;
   const int wg = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);   // (stat, group) index
   if (wg >= p.nstat * 32) return;
-  gn_finalize_group(p.partial, p.nslab, wg >> 5, wg & 31, p.C, p.count, p.eps, p.gamma, p.beta, p.ab, lane);
+  gn_finalize_group(p.partial, p.nslab, wg >> 5, wg & 31, p.C, p.count, p.eps, p.gamma, p.beta, p.ab, lane, p.mu);
 }
 
 struct GnApplyParams {
@@ -165,11 +167,16 @@ STAR_GLOBAL void gn_apply_kernel(const GnApplyParams p) {
 // A whole-chunk (5-D) GroupNorm WITHOUT activation that feeds only a Linear / Conv1d(k=1) -- TemporalTransformer.norm -> proj_in
 // (unet_v2v.py:1002-1005, 1052-1060) -- is an affine map per CHANNEL with one (a_c, b_c) for all rows (batch 1):
 //   proj_in(GN(x))[m][n] = sum_c W[n][c] (a_c x[m][c] + b_c) + bias[n] = (x W'^T)[m][n] + bias'[n],
-//   W'[n][c] = W[n][c] a_c (rounded to T),  bias'[n] = bias[n] + sum_c W[n][c] b_c.
+//   W'[n][c] = round_T(W[n][c] a_c),  bias'[n] = bias[n] + sum_c (W[n][c] b_c + (W[n][c] a_c - W'[n][c]) mu_c).
+// The last term is what keeps the fold as accurate as the unfolded path when a group's |mean| is large against its spread:
+// b_c = beta_c - a_c mu_c, so bias' = bias + sum_c W beta_c - sum_c W' mu_c -- the mean is subtracted with the ROUNDED weights the
+// GEMM really multiplies x by, i.e. y = sum_c W'[n][c] (x_c - mu_c) + const: the rounding error of W' scales with |x - mu|, not with
+// |x|  (without it a group at mean 30, std 1 lost 30x; tests/test_kernels.py::test_group_norm_fold_with_large_group_means).
 // The statistics pass stays; the apply pass (one read + one write of the activation) and the normalised tensor disappear: the
-// projection reads x itself.  One block per output row n; ab = the finalize kernel's per-channel pairs.
+// projection reads x itself.  One block per output row n; ab / mu = the finalize kernel's per-channel pairs and group means.
 struct GnFoldParams {
   const void* W; const float* bias; const float* ab; void* Wout; float* bias_out; int N, K;
+  const float* mu;   // [K] group mean per channel (nullptr: the plain fold)
 };
 template <class T>
 STAR_GLOBAL void gn_fold_weights_kernel(const GnFoldParams p) {
@@ -180,8 +187,11 @@ STAR_GLOBAL void gn_fold_weights_kernel(const GnFoldParams p) {
   float acc = 0.f;
   for (int k = t; k < p.K; k += blockDim.x) {
     const float wv = to_f32<T>(w[k]);
-    wo[k] = from_f32<T>(wv * p.ab[2 * k]);
+    const float wa = wv * p.ab[2 * k];
+    const T wr = from_f32<T>(wa);
+    wo[k] = wr;
     acc += wv * p.ab[2 * k + 1];
+    if (p.mu) acc += (wa - to_f32<T>(wr)) * p.mu[k];
   }
   red[t] = acc;
   block_sync();

@@ -75,11 +75,14 @@ int op_temporal_qkv_attn(Ctx* ctx, const TqArgs& a);
 // GroupNorm(32 groups) over channels-last rows; rows_per_stat = H*W (per frame) or F*H*W (whole chunk)
 int op_group_norm(Ctx* ctx, const void* x, int ldx, void* y, int ldy, const float* gamma, const float* beta,
                   int rows, int C, int rows_per_stat, float eps, bool silu);
-// statistics + finalize of a GroupNorm only: ab[nstat][C][2] = the per-channel affine pairs (y = x * a + b); nothing is applied
+// statistics + finalize of a GroupNorm only: ab[nstat][C][2] = the per-channel affine pairs (y = x * a + b); nothing is applied;
+// mu (optional) [nstat][C] = the channel's group mean
 int op_group_norm_stats(Ctx* ctx, const void* x, int ldx, const float* gamma, const float* beta, int rows, int C, int rows_per_stat,
-                        float eps, float* ab);
-// a whole-chunk GroupNorm folded into the Linear behind it (norm.h): Wout[n][k] = W[n][k] * ab[k][0], bias_out[n] = bias[n] + sum_k W[n][k] * ab[k][1]
-int op_gn_fold_weights(Ctx* ctx, const void* W, const float* bias, const float* ab, void* Wout, float* bias_out, int N, int K);
+                        float eps, float* ab, float* mu = nullptr);
+// a whole-chunk GroupNorm folded into the Linear behind it (norm.h): Wout[n][k] = round(W[n][k] * ab[k][0]),
+// bias_out[n] = bias[n] + sum_k W[n][k] * ab[k][1] (+ the rounding residual of Wout times mu[k]: the mean is subtracted with the rounded weights)
+int op_gn_fold_weights(Ctx* ctx, const void* W, const float* bias, const float* ab, void* Wout, float* bias_out, int N, int K,
+                       const float* mu = nullptr);
 int op_layer_norm(Ctx* ctx, const void* x, int ldx, void* y, int ldy, const float* gamma, const float* beta,
                   int rows, int C, float eps, int mode, const float* gate_w, float* maps, int H, int W, float* rowab = nullptr);
 int op_concat_add(Ctx* ctx, const void* a, const void* b, const void* c, void* out, int rows, int C1, int C2);

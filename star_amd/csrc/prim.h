@@ -312,6 +312,14 @@ STAR_DEV void wave_lds_order() {
 #endif
 
 // ---------------------------------------------------------------- buffer (descriptor) access
+// the wave gives up its issue slot for ~64 n cycles (n <= 127): start-phase staggering of resident workgroups
+STAR_DEV void wave_sleep(int n) {
+#ifndef STAR_HOSTEMU
+  for (; n > 0; n -= 127) __builtin_amdgcn_s_sleep(127);
+#else
+  (void)n;
+#endif
+}
 // 16-byte loads / stores through a buffer descriptor: lanes whose byte offset is >= the descriptor's range read zeros /
 // store nothing, so row and column tails need no exec-masked branches (hipcc then counts every vmcnt wait exactly).
 // base and bytes must be wave-uniform.
@@ -326,6 +334,7 @@ STAR_DEV u32x4 buf_load16(BufRsrc r, uint32_t voff) {
 STAR_DEV void buf_store16(BufRsrc r, uint32_t voff, u32x4 v) {
   if ((uint64_t)voff + 16 <= r.bytes) memcpy(r.base + voff, &v, 16);
 }
+template <int AUX> STAR_DEV void buf_store16_pol(BufRsrc r, uint32_t voff, u32x4 v) { buf_store16(r, voff, v); }
 #else
 using BufRsrc = __amdgpu_buffer_rsrc_t;
 STAR_DEV BufRsrc make_rsrc(const void* base, uint32_t bytes) {
@@ -333,6 +342,9 @@ STAR_DEV BufRsrc make_rsrc(const void* base, uint32_t bytes) {
 }
 STAR_DEV u32x4 buf_load16(BufRsrc r, uint32_t voff) { return __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0); }
 STAR_DEV void buf_store16(BufRsrc r, uint32_t voff, u32x4 v) { __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff, 0, 0); }
+// the same store with a cache policy (gfx94x / gfx950 aux bits: 1 = sc0, 2 = nt, 16 = sc1): 2 = non-temporal (streamed past the L2's
+// LRU), 16 = write-through to memory, 19 = all three
+template <int AUX> STAR_DEV void buf_store16_pol(BufRsrc r, uint32_t voff, u32x4 v) { __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff, 0, AUX); }
 #endif
 
 // LDS-DMA through a buffer descriptor (`buffer_load_dwordx4 v_off, s[rsrc], 0 offen lds`): like glds16, but the source is

@@ -218,15 +218,22 @@ struct Fwd : Runner {
     const int R = rows(x), C = s.C, I = s.inner, HW = x.H * x.W;
     const TBlockW& tb = s.tb;
     // GroupNorm over the whole chunk (no activation) feeds only proj_in: folded into its weights (norm.h: gn_fold_weights_kernel) --
-    // the statistics pass stays, the apply pass and the normalised tensor do not exist; proj_in reads x itself
+    // the statistics pass stays, the apply pass and the normalised tensor do not exist; proj_in reads x itself.  The group means are
+    // subtracted with the ROUNDED weights (bias'), so the fold is as accurate as norm + Linear for any mean / spread ratio.
+    // STAR_NO_GNFOLD=1: the unfolded pair (A/B switch, read once).
+    static const bool fold_gn = std::getenv("STAR_NO_GNFOLD") == nullptr;
     Act h = make(I, x.H, x.W);
-    {
-      Buf ab(ctx, (size_t)C * 2 * 4), w2(ctx, (size_t)I * C * es), b2(ctx, (size_t)I * 4);
-      if (!ab.p || !w2.p || !b2.p) { rc = ctx->fail("out of device memory (folded GroupNorm)"); return x; }
-      ok(op_group_norm_stats(ctx, x.p(), x.C, (const float*)s.norm.g.p, (const float*)s.norm.b.p, R, C, R, 1e-6f, ab.as<float>()));
-      ok(op_gn_fold_weights(ctx, s.proj_in.w.p, (const float*)s.proj_in.b.p, ab.as<float>(), w2.p, b2.as<float>(), I, C));
+    if (fold_gn) {
+      Buf ab(ctx, (size_t)C * 2 * 4), mu(ctx, (size_t)C * 4), w2(ctx, (size_t)I * C * es), b2(ctx, (size_t)I * 4);
+      if (!ab.p || !mu.p || !w2.p || !b2.p) { rc = ctx->fail("out of device memory (folded GroupNorm)"); return x; }
+      ok(op_group_norm_stats(ctx, x.p(), x.C, (const float*)s.norm.g.p, (const float*)s.norm.b.p, R, C, R, 1e-6f, ab.as<float>(), mu.as<float>()));
+      ok(op_gn_fold_weights(ctx, s.proj_in.w.p, (const float*)s.proj_in.b.p, ab.as<float>(), w2.p, b2.as<float>(), I, C, mu.as<float>()));
       LinW folded; folded.N = I; folded.K = C; folded.w.p = w2.p;
       gemm(x.p(), C, R, folded, h.p(), I, nullptr, 0, 0, b2.as<float>());
+    } else {
+      Act xn = make(C, x.H, x.W);
+      gn(x, s.norm, xn, true, 1e-6f, false);
+      gemm(xn.p(), C, R, s.proj_in, h.p(), I);
     }
     Act l = make(I, x.H, x.W);
     Buf qkv(ctx, (size_t)R * 3 * I * es), ab(ctx, (size_t)R * 2 * 4);

@@ -164,6 +164,9 @@ class FrozenOpenCLIPEmbedder(nn.Module):
             out = torch.empty_like(xin)
             ctx._check(ctx.lib.text_forward(ctx.h, L._ptr(xin), B, T, n_blocks - self.layer_idx, L._ptr(out)), "text_forward")
             return out.reshape(B, T, width).float().to(x.device)   # back on the caller's device (the tower's context may sit elsewhere)
+        blocks = self.model.transformer.resblocks        # the torch path after a HIP tower was built: its blocks were parked on the host
+        if next(blocks.parameters()).device != x.device:
+            blocks.to(x.device)
         x = x.permute(1, 0, 2)                           # NLD -> LND
         x = self.text_transformer_forward(x, attn_mask=self.model.attn_mask)
         x = x.permute(1, 0, 2)

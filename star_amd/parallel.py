@@ -181,6 +181,7 @@ def gather_frames(frames, group=None, source=None, ctx=None):
     if source is not None:
         from . import frames as _frames
         c = ctx if ctx is not None else _frames.context_for(frames.device)
+        c.use_current_stream()   # the collective below is ordered against torch's CURRENT stream: the colour fix must run on it too
         frames = c.color_fix(frames.float(), source.float(), as_uint8=True)
     frames = frames.contiguous()
     if dist.get_backend(group) == "gloo" and frames.is_cuda:   # plumbing tests on a 1-GPU box: stage through the host

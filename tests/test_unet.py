@@ -219,3 +219,30 @@ def test_illegal_latent_size_is_rejected(backend, request):
     dev = net.ctx.torch_device
     with pytest.raises(StarError):
         net(x.to(dev), t=t, y=y.to(dev), hint=hint.to(dev))
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+def test_group_norm_fold_with_large_group_means(backend, dtype, request):
+    """TemporalTransformer.norm folded into proj_in (norm.h: gn_fold_weights_kernel; unet_v2v.py:1002-1005,1052-1060) on an input
+    whose groups sit at |mean| = 10-40 x their spread, with non-trivial gamma / beta: the fold subtracts the group means with the
+    ROUNDED weights, so its error scales with |x - mean| like the unfolded norm + Linear (STAR_NO_GNFOLD=1), not with |x|.  Measured on
+    the transformer BRANCH (out - x) against the fp32 oracle on the same 16-bit-exact input.  (The plain fold W' = round(W a),
+    b' = b + W b_c fails this test: 3.4e-2 in f16.)"""
+    emu = request.getfixturevalue("emu_lib") if backend == "emu" else None
+    ctx = make_ctx(backend, dtype, emu)
+    b = torch.load(os.path.join(GOLD, "blocks.pt"))["tt_64_128"]
+    sd = {k: v.clone() for k, v in b["sd"].items()}
+    g = torch.Generator().manual_seed(77)
+    C = b["x"].shape[1]
+    sd["norm.weight"] = 0.5 + torch.rand(C, generator=g)
+    sd["norm.bias"] = torch.randn(C, generator=g) * 0.5
+    gmean = (10.0 + 30.0 * torch.rand(32, generator=g)) * (torch.randint(0, 2, (32,), generator=g) * 2 - 1)
+    x = 0.03 * (gmean.repeat_interleave(C // 32)[None, :, None, None] + torch.randn(b["x"].shape, generator=g))
+    x = x.to(dtype).float()                                  # exactly representable: the input rounding is not what is measured
+    y = run_module(ctx, "tt", sd, "m", x, heads=2, cout=C)
+    ref = O.temporal_transformer({"m." + k: v for k, v in sd.items()}, "m", x.permute(1, 0, 2, 3)[None], 2)[0].permute(1, 0, 2, 3)
+    branch, rbranch = y - x, ref - x
+    assert float(rbranch.abs().mean()) > 10 * float(x.abs().mean()) * 2.0 ** (-8 if dtype == torch.bfloat16 else -11)   # the branch is not lost in the residual's rounding
+    e = rel_rms(branch, rbranch)
+    assert e < (6e-3 if dtype == torch.float16 else 5e-2), e
+    ctx.close()
