@@ -55,6 +55,9 @@ size_t star_pool_peak_bytes(star_ctx* ctx);
 /* diagnostic: how many star_gemm / internal GEMM launches of this context were split into full rounds of big tiles + a remainder of
  * 128 x 128 tiles (see star_gemm_desc.force_tile) */
 int64_t star_gemm_split_count(star_ctx* ctx);
+/* diagnostic: how many GroupNorms of this context were finalized from their producer's partial statistics (star_gemm_gn / the
+ * forward's conv, temporal-conv and proj_out epilogues) instead of running a statistics pass over their input */
+int64_t star_gn_fused_count(star_ctx* ctx);
 
 /* ---- kernel-level entry points (unit parity; each is one HIP kernel family) */
 typedef struct star_gemm_desc {
@@ -77,6 +80,13 @@ typedef struct star_gemm_desc {
 /* replaces: nn.Linear / nn.Conv2d / nn.Conv3d(3,1,1) / nn.Conv1d(k=1) call sites
  * (unet_v2v.py:151-155,274,294,500,526,553,612,639,648,717,1005,1025,1209-1220) */
 int star_gemm(star_ctx* ctx, const star_gemm_desc* d);
+/* star_gemm whose epilogue ALSO writes the GroupNorm partial statistics of its output -- what the ResBlock / transformer layers in front
+ * of an nn.GroupNorm do in the forward (unet_v2v.py:609-640,1209-1220: conv / temporal conv / proj_out -> GroupNorm), so that the norm needs
+ * no statistics pass of its own.  gn_partial: fp32 [ceil(M / 32)][N / 2][2] = (sum, sum of squares) of the STORED 16-bit outputs over
+ * the 32 rows of a slot, per pair of adjacent channels.  The flavour exists for the 256 x 320, 128 x 128 and scheduled 256 x 256 tiles on
+ * plain / 3x3 / temporal-conv layers with the bias (+ residual) 16-bit epilogue; *wrote = 1 if the partials were written, 0 if the launcher's
+ * tile has no such flavour (the output is computed either way). */
+int star_gemm_gn(star_ctx* ctx, const star_gemm_desc* d, float* gn_partial, int32_t* wrote);
 
 
 /* replaces: xformers.ops.memory_efficient_attention(q,k,v) for spatial self- and text cross-attention
@@ -121,6 +131,11 @@ int star_temporal_qkv_attn(star_ctx* ctx, const star_tq_desc* d);
  * (unet_v2v.py:268,610,635,1002,1210-1219); rows_per_stat = H*W or F*H*W */
 int star_group_norm(star_ctx* ctx, const void* x, int32_t ldx, void* y, int32_t ldy, const float* gamma,
                     const float* beta, int32_t rows, int32_t C, int32_t rows_per_stat, float eps, int32_t silu);
+/* the same GroupNorm on a tensor whose producer wrote its partial statistics (star_gemm_gn): finalize from the partials (the rows of the
+ * 32-row slots that a statistics boundary cuts are re-read from x), then the apply pass -- two launches, x is read once.  C % 64 == 0. */
+int star_group_norm_from_partials(star_ctx* ctx, const void* x, int32_t ldx, void* y, int32_t ldy, const float* gamma,
+                                  const float* beta, int32_t rows, int32_t C, int32_t rows_per_stat, float eps, int32_t silu,
+                                  const float* gn_partial);
 /* replaces: nn.LayerNorm (unet_v2v.py:448-450) with the LIEM gates SpatialAttention (:380-394) /
  * TemporalLocalAttention (:396-411) fused in front.  mode: 0 plain, 1 linear gate, 2 7x7-map gate, 3 maps only */
 int star_layer_norm(star_ctx* ctx, const void* x, int32_t ldx, void* y, int32_t ldy, const float* gamma,

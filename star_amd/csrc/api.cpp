@@ -117,10 +117,12 @@ int star_pool_trim(star_ctx* h) {   // return the cached (free) blocks to the dr
 size_t star_pool_bytes(star_ctx* h) { return h->c.pool.total(); }
 size_t star_pool_peak_bytes(star_ctx* h) { return h->c.pool.peak(); }
 int64_t star_gemm_split_count(star_ctx* h) { return h ? (int64_t)h->c.gemm_splits : 0; }
+int64_t star_gn_fused_count(star_ctx* h) { return h ? (int64_t)h->c.gn_fused : 0; }
 
-int star_gemm(star_ctx* h, const star_gemm_desc* d) {
+static int gemm_from_desc(star_ctx* h, const star_gemm_desc* d, float* gn_partial, bool* gn_done) {
   if (h) rt::set_device(h->c.device);   // follow the context's device, not the caller's current one
   GemmArgs a;
+  a.gn_partial = gn_partial; a.gn_done = gn_done;
   a.A = d->A; a.W = d->W; a.C = d->C; a.bias = d->bias; a.res = d->res;
   a.M = d->M; a.N = d->N; a.K = d->K; a.lda = d->lda; a.ldc = d->ldc; a.ldr = d->ldr;
   a.mode = d->mode; a.H = d->H; a.Wd = d->Wd; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo;
@@ -129,6 +131,15 @@ int star_gemm(star_ctx* h, const star_gemm_desc* d) {
   if (a.force_tile >= 2000) { a.assume_cus = a.force_tile - 2000; a.force_tile = 18; }   // the persistent tile on that many resident workgroups (tests)
   else if (a.force_tile >= 1000) { a.assume_cus = a.force_tile - 1000; a.force_tile = 0; }   // automatic choice, rounds balanced for that many CUs (tests)
   return finish(h, op_gemm(&h->c, a));
+}
+int star_gemm(star_ctx* h, const star_gemm_desc* d) { return gemm_from_desc(h, d, nullptr, nullptr); }
+int star_gemm_gn(star_ctx* h, const star_gemm_desc* d, float* gn_partial, int32_t* wrote) {
+  bool done = false;
+  if (wrote) *wrote = 0;
+  if (!gn_partial) return finish(h, h->c.fail("gemm_gn: null partial buffer"));
+  const int rc = gemm_from_desc(h, d, gn_partial, &done);
+  if (wrote) *wrote = done ? 1 : 0;
+  return rc;
 }
 
 
@@ -156,6 +167,12 @@ int star_temporal_qkv_attn(star_ctx* h, const star_tq_desc* d) {
   a.A = d->A; a.W = d->W; a.O = d->O; a.bias = d->bias; a.colsum = d->colsum; a.rowab = d->rowab;
   a.lda = d->lda; a.ldo = d->ldo; a.HW = d->HW; a.F = d->F; a.C = d->C; a.heads = d->heads; a.scale = d->scale;
   return finish(h, op_temporal_qkv_attn(&h->c, a));
+}
+int star_group_norm_from_partials(star_ctx* h, const void* x, int32_t ldx, void* y, int32_t ldy, const float* gamma, const float* beta,
+                                  int32_t rows, int32_t C, int32_t rows_per_stat, float eps, int32_t silu, const float* gn_partial) {
+  if (h) rt::set_device(h->c.device);
+  if (!y) return finish(h, h->c.fail("group_norm_from_partials: null output"));
+  return finish(h, op_group_norm_fused(&h->c, x, ldx, y, ldy, gamma, beta, rows, C, rows_per_stat, eps, silu != 0, gn_partial));
 }
 int star_group_norm(star_ctx* h, const void* x, int32_t ldx, void* y, int32_t ldy, const float* gamma,
                     const float* beta, int32_t rows, int32_t C, int32_t rows_per_stat, float eps, int32_t silu) {

@@ -50,7 +50,7 @@ int op_gemm(Ctx* ctx, const GemmArgs& a) {
   ProfScope ps(ctx, a.mode == A_PLAIN ? PK_GEMM : (a.mode == A_TCONV3 ? PK_TCONV : PK_CONV), 2.0 * a.M * (double)a.N * a.K,
                ((double)a.M * (a.mode == A_PLAIN ? a.K : a.Cin) + (double)a.M * ((a.epi & EPI_GEGLU) ? a.N / 2 : a.N)) * 2.0,
                a.M, a.N, a.K, a.epi);
-  if ((a.force_tile >= 30 && a.force_tile <= 50) || (a.force_tile == 0 && gemm_astat_applies(a) && !gemm_env().no_astat)) return launch_gemm_astat(ctx, a);
+  if ((a.force_tile >= 29 && a.force_tile <= 50) || (a.force_tile == 0 && gemm_astat_applies(a) && !gemm_env().no_astat)) return launch_gemm_astat(ctx, a);
   if (a.group_m < 0 && gemm_env().has_group_m) {   // A/B aid: STAR_GEMM_GROUP_M overrides the automatic choice of the tile walk (gemm.h)
     GemmArgs b = a;
     b.group_m = gemm_env().group_m;

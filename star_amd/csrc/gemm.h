@@ -47,6 +47,10 @@ struct GemmParams {
   // c_n = bias[n]
   const float* rowab;   // [M][2]
   const float* colsum;  // [N]
+  // EPIF bit 4 (GroupNorm statistics in the producer's epilogue, norm.h: gn_finalize_fused_kernel): gn_partial[ceil(M / 32)][N / 2][2] =
+  // (sum, sum of squares) of the STORED 16-bit outputs over the 32 rows of a slot, per PAIR of adjacent channels (a GroupNorm group
+  // is an even number of channels, so a pair never straddles two groups).  Every (slot, pair) is written exactly once, in a fixed order.
+  float* gn_partial;
 };
 
 // exact (erf) GELU, F.gelu default (unet_v2v.py:504): gelu(x) = max(x, 0) - |x| q(|x|), q(t) = 0.5 erfc(t / sqrt 2).
@@ -100,7 +104,7 @@ STAR_DEV float gelu_tanh(float x) {
   return x * fast_rcp(1.0f + fast_exp2(-2.8853900817779268f * u));
 }
 
-template <class T, int BM, int BN, int WM, int WN, int AMODE, int MINW, bool F32OUT, bool STAGGER, int ABL = 0, int PIPE = 0, int EPIF = 0, int SCHED = 0>  // SCHED: hand-placed 2-stage loop for one wave per SIMD (4 waves x 128 x 128); ABL: ablation probes (bench only); PIPE: ring slots of the pipelined loop (0 = 2-stage loop); EPIF: 16-bit epilogue flavour (bit 0 residual add, bit 1 GEGLU, bit 2 tanh-GELU, bit 3 row-affine = folded LayerNorm)
+template <class T, int BM, int BN, int WM, int WN, int AMODE, int MINW, bool F32OUT, bool STAGGER, int ABL = 0, int PIPE = 0, int EPIF = 0, int SCHED = 0>  // SCHED: hand-placed 2-stage loop for one wave per SIMD (4 waves x 128 x 128); ABL: ablation probes (bench only); PIPE: ring slots of the pipelined loop (0 = 2-stage loop); EPIF: 16-bit epilogue flavour (bit 0 residual add, bit 1 GEGLU, bit 2 tanh-GELU, bit 3 row-affine = folded LayerNorm, bit 4 GroupNorm partial statistics of the output)
 STAR_GLOBAL void STAR_LAUNCH_BOUNDS(WM * WN * 64, MINW)
 gemm_kernel(const GemmParams p) {
   constexpr int NT = WM * WN * 64;
@@ -650,17 +654,39 @@ gemm_kernel(const GemmParams p) {
     constexpr int nchunks = 32 * cpr;
     static_assert(nchunks % 64 == 0, "a 32-row block must split evenly over the lanes");
     constexpr int RUN = nchunks / 64;                 // 16-B chunks per lane and 32-row block
+    // STATS: every lane keeps ONE chunk column cc for the whole block, so that its eight (sum, sum of squares) accumulators are per
+    // channel pair: a pass covers RPP = 64 / cpr whole rows (cpr = 20: 3 rows on 60 lanes, 11 passes instead of 10; for the
+    // power-of-two widths this IS the plain mapping)
+    constexpr bool STATS = (EPIF & 16) != 0;
+    static_assert(!STATS || !(GEGLUF || GELUTF || ROWAFF), "GroupNorm statistics: plain and residual epilogues only");
+    constexpr int RPP = 64 / cpr;
+    constexpr int NPASS = STATS ? (32 + RPP - 1) / RPP : RUN;
+    // chunk u of this lane in a 32-row block: (row, chunk column); false = the lane has no chunk in this pass (STATS mapping only)
+    auto chunk_of = [&](int u, int& row, int& cc) STAR_ALWAYS_INLINE -> bool {
+      if constexpr (STATS) {
+        const int r0 = lane / cpr;
+        cc = lane - r0 * cpr;
+        row = u * RPP + r0;
+        const bool act = r0 < RPP && row < 32;
+        if (row > 31) row = 31;
+        return act;
+      } else {
+        const int q = lane + 64 * u;
+        row = q / cpr; cc = q - row * cpr;
+        return true;
+      }
+    };
     const float* bias_lds = reinterpret_cast<const float*>(smem + SMEM_LOOP) + wn * WTN;
     block_sync();                                     // all MFMA reads of the stages are done
     char* my = smem + wave * (32 * pitch);
 
-    vec<T, 8> rv[RESF ? TM : 1][RESF ? RUN : 1];
+    vec<T, 8> rv[RESF ? TM : 1][RESF ? NPASS : 1];
     auto load_res = [&](int i) STAR_ALWAYS_INLINE {
       if constexpr (RESF) {
 #pragma unroll
-        for (int u = 0; u < RUN; ++u) {
-          const int q = lane + 64 * u;
-          const int row = q / cpr, cc = q - row * cpr;
+        for (int u = 0; u < NPASS; ++u) {
+          int row, cc;
+          (void)chunk_of(u, row, cc);
           int m = m0 + wm * WTM + i * 32 + row, n = out_n0 + cc * 8;
           if (m > p.M - 1) m = p.M - 1;
           if (n > N_out - 8) n = N_out - 8;
@@ -669,10 +695,13 @@ gemm_kernel(const GemmParams p) {
       }
     };
     auto store_block = [&](int i) STAR_ALWAYS_INLINE {
+      float ps[4], pq[4];   // STATS: this lane's chunk column, 4 channel pairs: sum / sum of squares over its rows of the block
 #pragma unroll
-      for (int u = 0; u < RUN; ++u) {
-        const int q = lane + 64 * u;
-        const int row = q / cpr, cc = q - row * cpr;
+      for (int e = 0; e < 4; ++e) { ps[e] = 0.f; pq[e] = 0.f; }
+#pragma unroll
+      for (int u = 0; u < NPASS; ++u) {
+        int row, cc;
+        const bool act = chunk_of(u, row, cc);
         const int m = m0 + wm * WTM + i * 32 + row, n = out_n0 + cc * 8;
         const vec<T, 4> lo = *reinterpret_cast<const vec<T, 4>*>(my + row * pitch + cc * 16);
         const vec<T, 4> hi = *reinterpret_cast<const vec<T, 4>*>(my + row * pitch + cc * 16 + 8);
@@ -683,7 +712,42 @@ gemm_kernel(const GemmParams p) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) ov[e] = from_f32<T>(to_f32<T>(ov[e]) + to_f32<T>(rv[i][u][e]));
         }
-        if (m < p.M && n < N_out && (ABL != 5 || p.M < 0)) *reinterpret_cast<vec<T, 8>*>((T*)p.C + (size_t)m * p.ldc + n) = ov;
+        if (act && m < p.M && n < N_out && (ABL != 5 || p.M < 0)) {
+          *reinterpret_cast<vec<T, 8>*>((T*)p.C + (size_t)m * p.ldc + n) = ov;
+          if constexpr (STATS) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              vec<T, 2> pr;
+              pr[0] = ov[2 * e]; pr[1] = ov[2 * e + 1];
+              ps[e] = dot2_one<T>(pr, ps[e]);
+              pq[e] = dot2_acc<T>(pr, pr, pq[e]);
+            }
+          }
+        }
+      }
+      if constexpr (STATS) {
+        // the RPP lanes of a chunk column (lane, lane + cpr, ...) -> the first of them, in a fixed order; one slot row per 32-row block
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if constexpr ((cpr & (cpr - 1)) == 0) {
+#pragma unroll
+            for (int mk = cpr; mk < 64; mk <<= 1) { ps[e] += shfl_xor(ps[e], mk); pq[e] += shfl_xor(pq[e], mk); }
+          } else {
+            float s0 = ps[e], q0 = pq[e];
+#pragma unroll
+            for (int k = 1; k < RPP; ++k) { s0 += shfl(ps[e], (lane + k * cpr) & 63); q0 += shfl(pq[e], (lane + k * cpr) & 63); }
+            ps[e] = s0; pq[e] = q0;
+          }
+        }
+        const int row0 = m0 + wm * WTM + i * 32, n = out_n0 + lane * 8;
+        if (lane < cpr && row0 < p.M && n < N_out) {
+          float* dst = p.gn_partial + (size_t)(row0 >> 5) * p.N + n;
+          f32x4 a, b;
+          a[0] = ps[0]; a[1] = pq[0]; a[2] = ps[1]; a[3] = pq[1];
+          b[0] = ps[2]; b[1] = pq[2]; b[2] = ps[3]; b[3] = pq[3];
+          *reinterpret_cast<f32x4*>(dst) = a;
+          *reinterpret_cast<f32x4*>(dst + 4) = b;
+        }
       }
     };
 

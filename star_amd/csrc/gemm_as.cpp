@@ -35,12 +35,16 @@ static int launch_astat(Ctx* ctx, const GemmArgs& a) {
     if (a.epi & EPI_GEGLU) STAR_LAUNCH((gemm_astat_kernel<T, 1, 6>), grid, block, smem, ctx->stream, p); else STAR_LAUNCH((gemm_astat_kernel<T, 0, 6>), grid, block, smem, ctx->stream, p);
     return 0;
   }
+  if (a.force_tile == 29) {   // the round-4 kernel: plain stores, lockstep start (A/B reference)
+    if (a.epi & EPI_GEGLU) STAR_LAUNCH((gemm_astat_kernel<T, 1, 12>), grid, block, smem, ctx->stream, p); else STAR_LAUNCH((gemm_astat_kernel<T, 0, 12>), grid, block, smem, ctx->stream, p);
+    return 0;
+  }
   if (a.force_tile >= 47 && a.force_tile <= 50) {   // round 5 (correct results): staggered first round, 1 / 2 / 4 / 8 sleep units (127 x 64 cycles) per phase
     p.group_m = 1 << (a.force_tile - 47);
     if (a.epi & EPI_GEGLU) STAR_LAUNCH((gemm_astat_kernel<T, 1, 11>), grid, block, smem, ctx->stream, p); else STAR_LAUNCH((gemm_astat_kernel<T, 0, 11>), grid, block, smem, ctx->stream, p);
     return 0;
   }
-  if (a.force_tile >= 43 && a.force_tile <= 46) {   // round 5 (correct results): 43 / 44 / 45 = the flush's stores non-temporal / write-through / both; 46 = every per-tile wait is vmcnt(0)
+  if (a.force_tile >= 43 && a.force_tile <= 46) {   // round 5 (correct results): 43 / 44 / 45 = the flush's stores plain / write-through / write-through + nt (the product's are nt); 46 = every per-tile wait is vmcnt(0)
     const bool g = (a.epi & EPI_GEGLU) != 0;
     switch (a.force_tile) {
       case 43: if (g) STAR_LAUNCH((gemm_astat_kernel<T, 1, 7>), grid, block, smem, ctx->stream, p); else STAR_LAUNCH((gemm_astat_kernel<T, 0, 7>), grid, block, smem, ctx->stream, p); break;
@@ -65,7 +69,7 @@ static int launch_astat(Ctx* ctx, const GemmArgs& a) {
     return 0;
   }
 #else
-  if (a.force_tile > 30) return ctx->fail("gemm (A-stationary): ablation ids exist only in the bench build");
+  if (a.force_tile > 30 || a.force_tile == 29) return ctx->fail("gemm (A-stationary): ablation ids exist only in the bench build");
 #endif
   if (a.epi & EPI_GEGLU) STAR_LAUNCH((gemm_astat_kernel<T, 1>), grid, block, smem, ctx->stream, p);
   else STAR_LAUNCH((gemm_astat_kernel<T, 0>), grid, block, smem, ctx->stream, p);

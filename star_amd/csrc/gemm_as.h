@@ -34,20 +34,23 @@ STAR_GLOBAL void STAR_LAUNCH_BOUNDS(256, 1)
 gemm_astat_kernel(const GemmParams p) {
   constexpr int ABL = ABL_ >= 6 ? 0 : ABL_;     // 6: the product paths everywhere except the global stores
   constexpr bool NOSTORE = ABL_ == 6;
-  // 7 / 8 / 9 (round 5, correct results): the flush's stores with a cache policy -- non-temporal / write-through / both (prim.h:
-  // buf_store16_pol); 10: every per-tile wait drains ALL vector-memory operations (vmcnt(0): how much is the counted wait worth?)
-  constexpr int STPOL = ABL_ == 7 ? 2 : ABL_ == 8 ? 16 : ABL_ == 9 ? 19 : 0;
-  constexpr bool DRAIN_ALL = ABL_ == 10;
-  // 11 (round 5, correct results): the FIRST round of workgroups starts staggered.  Every workgroup does the same work, so all 256 CUs run
-  // in lockstep: their A-panel prologues (164 KB per CU, 42 MB at once) are one HBM burst during which nobody computes (~14 us of the
-  // ~33 us a workgroup lives at N = 960).  Phase p = (blockIdx / 8) % 8 of the first 256 workgroups sleeps p * group_m * 127 * 64 cycles;
-  // later workgroups inherit the phase of the one they replace.
-  constexpr bool STAGGER = ABL_ == 11;
-  if constexpr (STAGGER) {
-    if (blockIdx.x < 256) wave_sleep(((int)(blockIdx.x >> 3) & 7) * p.group_m * 127);
-  }
   constexpr int K = 320, KS = K / 16, SLAB = 64 * 128, WTILE = (K / 64) * SLAB;   // 40 KB per 64-row W tile
   constexpr int STG = 64 * 128;                 // per-wave staging block: 64 rows x 64 outputs (GEGLU: two W tiles fill it)
+  // Round 5 (profiles/r05_cbench_astat_*.txt, r05_pmc_astat.txt): half of a wave's life in this kernel is an s_waitcnt, and it is vector
+  // memory, not the LDS (SQ_WAIT_INST_LDS 4 %); WITHOUT its global stores the kernel is 23 % faster at N = 960 (tile 41).  Two cheap,
+  // bit-identical measures ship: the flush's stores are NON-TEMPORAL (aux nt: the 1.6 GB output streams past the L2 instead of evicting
+  // the W panel and the next rows of A; +4.5 % at N = 960, +1.7 % at N = 2560; write-through sc1 loses 2.6 %) and the FIRST round of
+  // workgroups starts staggered (every workgroup does the same work, so the 256 CUs ran their A-panel prologues -- 42 MB at once, nobody
+  // computing -- in lockstep: phase (blockIdx / 8) % 8 sleeps phase x 8128 cycles; +2.9 % / +0.3 %, longer delays lose; only launches of >= 1024 workgroups, where the last phase's 27 us are small).  The counted
+  // per-tile wait is worth 2.3 % against vmcnt(0) (tile 46): store LATENCY is not what is left.
+  // ABL_ 7 / 8 / 9: stores plain (the round-4 kernel's) / write-through / write-through + nt;  10: every per-tile wait is vmcnt(0);
+  // 11: stagger unit from p.group_m (1, 2, 4, 8);  12: the round-4 kernel (plain stores, no stagger)
+  constexpr int STPOL = (ABL_ == 7 || ABL_ == 12) ? 0 : ABL_ == 8 ? 16 : ABL_ == 9 ? 19 : 2;
+  constexpr bool DRAIN_ALL = ABL_ == 10;
+  constexpr bool STAGGER = ABL_ != 12;
+  if constexpr (STAGGER) {
+    if (blockIdx.x < 256 && gridDim.x >= 1024) wave_sleep(((int)(blockIdx.x >> 3) & 7) * (ABL_ == 11 ? p.group_m : 1) * 127);
+  }
   char* smem = dyn_smem();
   char* stg = smem + 2 * WTILE + wave_uniform((int)threadIdx.x >> 6) * STG;
   float* bias_lds = reinterpret_cast<float*>(smem + 2 * WTILE + 4 * STG);   // bias[N] | colsum[N]

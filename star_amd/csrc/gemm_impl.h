@@ -9,7 +9,8 @@ namespace star {
 
 // ALLEPI: also instantiate the tanh-GELU and folded-LayerNorm epilogue flavours (the auto-selected tiles 1-4 only: every
 // flavour is one more kernel per tile, mode and dtype, and these are the longest compiles of the build)
-template <class T, int BM, int BN, int WM, int WN, int MINW, bool F32OUT, bool STAGGER, int PIPE = 0, bool ALLEPI = false, int SCHED = 0, int ABLV = 0>
+// GNS: also instantiate the GroupNorm-statistics flavours (EPIF 16 / 17) of the plain / 3x3 / temporal-conv modes (tiles 2, 3 and 17)
+template <class T, int BM, int BN, int WM, int WN, int MINW, bool F32OUT, bool STAGGER, int PIPE = 0, bool ALLEPI = false, int SCHED = 0, int ABLV = 0, bool GNS = false>
 static int launch_gemm_f(Ctx* ctx, const GemmArgs& a) {
   GemmParams p{};
   p.A = a.A; p.W = a.W; p.C = a.C; p.bias = a.bias; p.res = a.res; p.zero_page = ctx->zero_page;
@@ -17,6 +18,7 @@ static int launch_gemm_f(Ctx* ctx, const GemmArgs& a) {
   p.H = a.H; p.Wd = a.Wd; p.Cin = a.Cin; p.Ho = a.Ho; p.Wo = a.Wo; p.stride = a.stride; p.pad_t = a.pad_t; p.pad_l = a.pad_l;
   p.HW = a.HW; p.F = a.F; p.up_crop = a.up_crop; p.epi = a.epi;
   p.rowab = a.rowab; p.colsum = a.colsum;
+  p.gn_partial = a.gn_partial;
   p.m_off = a.m_off;
   p.tiles_m = ((a.m_end > 0 ? a.m_end : a.M) - a.m_off + BM - 1) / BM;
   p.tiles_n = (a.N + BN - 1) / BN;
@@ -37,6 +39,18 @@ static int launch_gemm_f(Ctx* ctx, const GemmArgs& a) {
   if (rowaff && (res || gelut || a.mode != A_PLAIN || !a.rowab || !a.colsum || !(a.epi & EPI_BIAS)))
     return ctx->fail("gemm: the folded-LayerNorm epilogue is for plain-A layers without a residual and needs rowab, colsum and bias");
 #define STAR_GEMM_GO(MODE, EF) STAR_LAUNCH((gemm_kernel<T, BM, BN, WM, WN, MODE, MINW, F32OUT, STAGGER, ABLV, PIPE, EF, SCHED>), grid, block, smem, ctx->stream, p)
+  if (a.gn_partial) {   // the caller (launch_gemm) has checked mode and epilogue; the flavour exists for GNS tiles only
+    if constexpr (GNS && !F32OUT) {
+      switch (a.mode) {
+        case A_PLAIN: if (res) STAR_GEMM_GO(A_PLAIN, 17); else STAR_GEMM_GO(A_PLAIN, 16); break;
+        case A_CONV3X3: if (res) STAR_GEMM_GO(A_CONV3X3, 17); else STAR_GEMM_GO(A_CONV3X3, 16); break;
+        case A_TCONV3: if (res) STAR_GEMM_GO(A_TCONV3, 17); else STAR_GEMM_GO(A_TCONV3, 16); break;
+        default: return ctx->fail("gemm: no GroupNorm-statistics flavour of this mode");
+      }
+      if (a.gn_done) *a.gn_done = true;
+      return 0;
+    } else return ctx->fail("gemm: this tile has no GroupNorm-statistics flavour");
+  }
   switch (a.mode) {
     case A_PLAIN:
       if constexpr (F32OUT) STAR_GEMM_GO(A_PLAIN, 0);
@@ -67,10 +81,10 @@ static int launch_gemm_f(Ctx* ctx, const GemmArgs& a) {
   return 0;
 }
 
-template <class T, int BM, int BN, int WM, int WN, int MINW, bool STAGGER = false, int PIPE = 0, bool ALLEPI = false>
+template <class T, int BM, int BN, int WM, int WN, int MINW, bool STAGGER = false, int PIPE = 0, bool ALLEPI = false, bool GNS = false>
 static int launch_gemm_t(Ctx* ctx, const GemmArgs& a) {
   if (a.epi & EPI_OUT_F32) return launch_gemm_f<T, BM, BN, WM, WN, MINW, true, false, 0>(ctx, a);
-  return launch_gemm_f<T, BM, BN, WM, WN, MINW, false, STAGGER, PIPE, ALLEPI>(ctx, a);
+  return launch_gemm_f<T, BM, BN, WM, WN, MINW, false, STAGGER, PIPE, ALLEPI, 0, 0, GNS>(ctx, a);
 }
 
 int launch_gemm_persist(Ctx* ctx, const GemmArgs& a);   // gemm_p.cpp
@@ -107,7 +121,7 @@ static int launch_gemm(Ctx* ctx, const GemmArgs& a) {
     // to the 256 x 320 tile (N = 640 would waste a sixth of three 256-column tiles)
     // ... and whose tiles fill the resident workgroups' rounds to >= 88 % (the persistent walk is static: 1080 tiles on 256 CUs are 5
     // rounds for some workgroups; there the 256 x 320 tile + tail split measured ahead, profiles/r04_gemm_ab_v3_auto.txt)
-    bool persist_ok = gemm_persist_covers(a) && a.K >= 512 && a.N % 256 == 0 && a.N >= 1024 && !no_persist_env();
+    bool persist_ok = gemm_persist_covers(a) && a.K >= 512 && a.N % 256 == 0 && a.N >= 1024 && !no_persist_env() && !a.gn_partial;
     if (persist_ok) {
       const int cus = a.assume_cus > 0 ? a.assume_cus : (ctx->num_cus > 0 ? ctx->num_cus : 256);
       const int64_t nt = (int64_t)((a.M + 255) / 256) * (a.N / 256), rounds = (nt + cus - 1) / cus;
@@ -122,6 +136,14 @@ static int launch_gemm(Ctx* ctx, const GemmArgs& a) {
     // 843264 x 2560 x 320, profiles/r02_gemm_tiles_after_valu.txt)
     else if (a.N <= 128) tile = 4;
     else tile = 1;
+  }
+  // GroupNorm statistics in the epilogue: the flavour exists for tiles 2, 3 and 17 on plain / 3x3 / temporal-conv layers with the
+  // bias (+ residual) 16-bit epilogue; elsewhere the request is dropped (gn_done stays false: the consumer runs its own pass)
+  if (a.gn_partial && (!(tile == 2 || tile == 3 || tile == 17) || !(a.mode == A_PLAIN || a.mode == A_CONV3X3 || a.mode == A_TCONV3) ||
+                       (a.epi & (EPI_OUT_F32 | EPI_ROWAFF | EPI_GELU_TANH | EPI_GEGLU)) || (a.N & 7))) {
+    GemmArgs b = a;
+    b.gn_partial = nullptr;
+    return launch_gemm<T>(ctx, b);
   }
   // ---- tail split.  The big tiles run ONE workgroup per CU, so a launch is ceil(tiles / CUs) rounds and the last round can be mostly
   // empty: the 1280-wide layers of level 2 (M = 55296: 864 tiles of 256 x 320 = 3.4 rounds, 1080 of 256 x 256 = 4.2) spent 16 % of
@@ -159,13 +181,13 @@ static int launch_gemm(Ctx* ctx, const GemmArgs& a) {
     // 8 waves per workgroup (2 per SIMD, <= 256 VGPRs each; 192 / 236 used, no spills): measured 1.3-3.6x faster than
     // 4-wave variants of the same tiles on the K = 320 layers (profiles/r01_gemm_tile_sweep.txt)
     case 1: return launch_gemm_t<T, 256, 256, 4, 2, 2, false, 0, true>(ctx, a);
-    case 2: return launch_gemm_t<T, 256, 320, 4, 2, 2, false, 0, true>(ctx, a);
+    case 2: return launch_gemm_t<T, 256, 320, 4, 2, 2, false, 0, true, true>(ctx, a);
     // 4 waves x (128 x 128), one wave per SIMD, hand-placed 2-stage loop (gemm.h SCHED): plain / 3x3 conv / temporal conv, 16-bit output
     case 17:
       if (a.epi & (EPI_OUT_F32 | EPI_ROWAFF | EPI_GELU_TANH | EPI_GEGLU)) return ctx->fail("gemm: tile 17 has the plain and residual 16-bit epilogues only");
-      return launch_gemm_f<T, 256, 256, 2, 2, 1, false, false, 0, false, 1>(ctx, a);
+      return launch_gemm_f<T, 256, 256, 2, 2, 1, false, false, 0, false, 1, 0, true>(ctx, a);
     case 18: return launch_gemm_persist(ctx, a);   // persistent one-wave-per-SIMD tile with a wave-private epilogue (gemm_p.h)
-    case 3: return launch_gemm_t<T, 128, 128, 2, 2, 2, false, 0, true>(ctx, a);
+    case 3: return launch_gemm_t<T, 128, 128, 2, 2, 2, false, 0, true, true>(ctx, a);
     case 4: return launch_gemm_t<T, 256, 128, 4, 1, 1, false, 0, true>(ctx, a);
 #ifdef STAR_BENCH_VARIANTS   // A/B experiments of round 1 / 2 that lost to the tiles above (profiles/r01_gemm_ablation.txt, r02_gemm8_ablation.txt)
     case 5: return launch_gemm_t<T, 256, 256, 4, 2, 2, true>(ctx, a);   // staggered wave groups (A/B)

@@ -4,6 +4,7 @@
 #pragma once
 #include "ops.h"
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -236,8 +237,11 @@ struct Builder {
 
 struct Act {          // an activation tensor: rows = F*H*W tokens; the buffer returns to the pool with its last owner
   std::shared_ptr<Buf> buf; int C = 0, H = 0, W = 0;
+  // GroupNorm partial statistics of THIS tensor, written by the kernel that produced it (GemmArgs::gn_partial): a GroupNorm that
+  // reads the tensor finalizes from them instead of running its own statistics pass; null = none
+  std::shared_ptr<Buf> gnp;
   void* p() const { return buf ? buf->p : nullptr; }
-  void drop() { buf.reset(); }
+  void drop() { buf.reset(); gnp.reset(); }
 };
 
 
@@ -258,19 +262,32 @@ struct Runner {
   }
   int rows(const Act& a) const { return F * a.H * a.W; }
   void ok(int r) { if (r && !rc) rc = r; }
+  // GroupNorm statistics in the producers' epilogues (STAR_NO_GNEPI=1: every GroupNorm runs its own statistics pass; A/B switch, read once)
+  static bool gn_epi_enabled() { static const bool v = std::getenv("STAR_NO_GNEPI") == nullptr; return v; }
+  // op_gemm producing y; `stats`: also ask for y's GroupNorm partials (kept on y only if the launched tile wrote them)
+  void gemm_to(GemmArgs& g, Act* y, bool stats) {
+    bool done = false;
+    std::shared_ptr<Buf> part;
+    if (stats && y && gn_epi_enabled() && !(g.N & 63)) {
+      part = std::make_shared<Buf>(ctx, (size_t)((g.M + 31) / 32) * g.N * sizeof(float));
+      if (part->p) { g.gn_partial = part->as<float>(); g.gn_done = &done; }
+    }
+    ok(op_gemm(ctx, g));
+    if (y) y->gnp = done ? part : nullptr;
+  }
 
   // y = x W^T (+b) (+res)
   void gemm(const void* A, int lda, int M, const LinW& w, void* C, int ldc, const void* res = nullptr, int ldr = 0, int extra_epi = 0,
-            const float* bias_override = nullptr) {
+            const float* bias_override = nullptr, Act* stats_of = nullptr) {   // stats_of: the Act that C is (dense, ldc == N): ask for its GroupNorm partials
     GemmArgs g;
     g.A = A; g.W = w.w.p; g.C = C; g.M = M; g.N = w.N; g.K = w.K; g.lda = lda; g.ldc = ldc;
     g.bias = bias_override ? bias_override : (const float*)w.b.p;
     g.res = res; g.ldr = ldr;
     g.epi = (g.bias ? EPI_BIAS : 0) | (res ? EPI_RES : 0) | extra_epi;
-    ok(op_gemm(ctx, g));
+    gemm_to(g, stats_of, stats_of != nullptr);
   }
   void conv3x3(const Act& x, const LinW& w, Act& y, int mode, int stride, int pad_t, int pad_l, const void* res, const float* bias_override = nullptr,
-               int extra_epi = 0, void* out_override = nullptr, int ldc_override = 0, int up_crop = 1) {
+               int extra_epi = 0, void* out_override = nullptr, int ldc_override = 0, int up_crop = 1, bool stats = false) {
     GemmArgs g;
     g.up_crop = up_crop;
     g.A = x.p(); g.W = w.w.p; g.C = out_override ? out_override : y.p();
@@ -279,11 +296,14 @@ struct Runner {
     g.bias = bias_override ? bias_override : (const float*)w.b.p;
     g.res = res; g.ldr = y.C;
     g.epi = (g.bias ? EPI_BIAS : 0) | (res ? EPI_RES : 0) | extra_epi;
-    ok(op_gemm(ctx, g));
+    gemm_to(g, (out_override || ldc_override) ? nullptr : &y, stats && !out_override && !ldc_override);
   }
   void gn(const Act& x, const NormW& n, Act& y, bool whole_chunk, float eps, bool silu) {
     const int rps = whole_chunk ? F * x.H * x.W : x.H * x.W;
-    ok(op_group_norm(ctx, x.p(), x.C, y.p(), y.C, (const float*)n.g.p, (const float*)n.b.p, rows(x), x.C, rps, eps, silu));
+    if (x.gnp && x.gnp->p)   // the producer of x left its partial statistics: finalize from them, no statistics pass
+      ok(op_group_norm_fused(ctx, x.p(), x.C, y.p(), y.C, (const float*)n.g.p, (const float*)n.b.p, rows(x), x.C, rps, eps, silu, x.gnp->as<float>()));
+    else
+      ok(op_group_norm(ctx, x.p(), x.C, y.p(), y.C, (const float*)n.g.p, (const float*)n.b.p, rows(x), x.C, rps, eps, silu));
   }
   void ln(const void* x, void* y, int rws, int C, const NormW& n, int mode = LN_PLAIN, const float* gw = nullptr, float* maps = nullptr, int H = 0, int W = 0) {
     ok(op_layer_norm(ctx, x, C, y, C, (const float*)n.g.p, (const float*)n.b.p, rws, C, 1e-5f, mode, gw, maps, H, W));

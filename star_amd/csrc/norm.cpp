@@ -44,6 +44,53 @@ static int gn_t(Ctx* ctx, const void* x, int ldx, void* y, int ldy, const float*
   return 0;
 }
 
+// GroupNorm whose statistics come from the producer's epilogue (gn_partial: gemm.h EPIF bit 4): finalize from the partials (+ the rows
+// of the slots a stat boundary cuts), then the apply pass; y == nullptr: finalize only (ab_out / mu_out, for the weight fold)
+template <class T>
+static int gn_fused_t(Ctx* ctx, const void* x, int ldx, void* y, int ldy, const float* gamma, const float* beta, int rows, int C,
+                      int rows_per_stat, float eps, bool silu, const float* partial, float* ab_out, float* mu_out) {
+  const int nstat = rows / rows_per_stat;
+  Buf ab(ctx, ab_out ? 0 : (size_t)nstat * C * 2 * sizeof(float));
+  float* abp = ab_out ? ab_out : ab.as<float>();
+  if (!abp) return ctx->fail("group_norm: out of device memory");
+  const double count = (double)rows_per_stat * (C / 32);
+  // enough workgroups to fill the chip: a whole-chunk norm (nstat = 1, 26 352 slots at level 0) is split into parts along the slots,
+  // reduced by the stand-alone path's finalize kernel (fixed order)
+  int split = 1;
+  while (nstat * 32 * split < 1024 && (rows_per_stat >> 5) / (split * 2) >= 64) split *= 2;
+  Buf parts(ctx, split > 1 ? (size_t)nstat * 32 * split * 2 * sizeof(double) : 0);
+  if (split > 1 && !parts.p) return ctx->fail("group_norm: out of device memory");
+  GnFinalizeFusedParams fp{partial, x, ldx, gamma, beta, abp, mu_out, C, nstat, rows_per_stat, count, eps, split, parts.as<double>()};
+  const int nthr = 256;
+  STAR_LAUNCH((gn_finalize_fused_kernel<T>), dim3((unsigned)(nstat * 32 * split)), dim3((unsigned)nthr), (size_t)nthr * 16, ctx->stream, fp);
+  if (split > 1) {
+    GnFinalizeParams f2{parts.as<double>(), gamma, beta, abp, C, nstat, split, count, eps, mu_out};
+    STAR_LAUNCH(gn_finalize_kernel, dim3((unsigned)((nstat * 32 + 3) / 4)), dim3(256), (size_t)0, ctx->stream, f2);
+  }
+  if (!y) return 0;
+  const int CC8 = C / 8;
+  int RL = 256 / CC8; if (RL < 1) RL = 1;
+  int slab = 256;
+  while ((long long)((rows_per_stat + slab - 1) / slab) * nstat < 1024 && slab > 32) slab >>= 1;
+  const int nslab = (rows_per_stat + slab - 1) / slab;
+  GnApplyParams ap{x, y, abp, ldx, ldy, C, rows_per_stat, slab, silu ? 1 : 0};
+  STAR_LAUNCH((gn_apply_kernel<T>), dim3((unsigned)nslab, (unsigned)nstat), dim3((unsigned)(CC8 * RL)), (size_t)0, ctx->stream, ap);
+  return 0;
+}
+
+int op_group_norm_fused(Ctx* ctx, const void* x, int ldx, void* y, int ldy, const float* gamma, const float* beta, int rows, int C,
+                        int rows_per_stat, float eps, bool silu, const float* partial, float* ab_out, float* mu_out) {
+  if (C % 64) return ctx->fail("group_norm (fused statistics): C must be a multiple of 64 (an even number of channels per group)");
+  if (rows % rows_per_stat) return ctx->fail("group_norm: rows not a multiple of rows_per_stat");
+  if ((ldx | (y ? ldy : 8)) & 7) return ctx->fail("group_norm: row strides must be multiples of 8");
+  if (C / 8 > 1024) return ctx->fail("group_norm: C too large");
+  if (!partial || (!y && !ab_out)) return ctx->fail("group_norm (fused statistics): null argument");
+  ++ctx->gn_fused;
+  ProfScope ps(ctx, PK_GN, 0.0, (y ? 2.0 : 0.0) * rows * (double)C * 2.0 + (double)((rows + 31) / 32) * C * 4.0);
+  if (ctx->dtype == DT_F16) return gn_fused_t<f16>(ctx, x, ldx, y, ldy, gamma, beta, rows, C, rows_per_stat, eps, silu, partial, ab_out, mu_out);
+  return gn_fused_t<bf16>(ctx, x, ldx, y, ldy, gamma, beta, rows, C, rows_per_stat, eps, silu, partial, ab_out, mu_out);
+}
+
 int op_group_norm(Ctx* ctx, const void* x, int ldx, void* y, int ldy, const float* gamma, const float* beta,
                   int rows, int C, int rows_per_stat, float eps, bool silu) {
   if (C % 32 || C % 8) return ctx->fail("group_norm: C must be a multiple of 32");

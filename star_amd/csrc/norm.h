@@ -119,6 +119,82 @@ STAR_GLOBAL void gn_finalize_kernel(const GnFinalizeParams p) {
   gn_finalize_group(p.partial, p.nslab, wg >> 5, wg & 31, p.C, p.count, p.eps, p.gamma, p.beta, p.ab, lane, p.mu);
 }
 
+// ------------------------------------------------------------------ GroupNorm finalize from the PRODUCER's partial statistics
+// The GEMM-family kernel that wrote x also wrote, per 32-row slot and channel pair, (sum, sum of squares) of the stored values
+// (gemm.h EPIF bit 4: gn_partial[ceil(rows / 32)][C / 2][2]) -- the statistics pass over x (a third of a GroupNorm's traffic) is
+// gone.  One workgroup per (stat, group): the slots that lie wholly inside the stat's rows are summed from the partials, the at most
+// 2 x 31 rows of the two slots a stat boundary cuts through (a frame of 26 352 rows is 823.5 slots) are read from x itself.
+// Fixed assignment of items to threads and a fixed tree over the threads: bit-identical from launch to launch.
+struct GnFinalizeFusedParams {
+  const float* partial; const void* x; int ldx;
+  const float* gamma; const float* beta; float* ab; float* mu;   // ab[nstat][C][2]; mu optional [nstat][C]
+  int C; int nstat; int rows_per_stat; double count; float eps;
+  // split > 1 (a whole-chunk norm: one stat of 26 352 slots at level 0 would otherwise be summed by 32 workgroups): workgroup
+  // (stat, group, part) sums a contiguous 1 / split of the whole slots and writes its two doubles to part_out[(stat * 32 + group) * split + part]
+  // (= the layout gn_finalize_kernel reduces: nslab = split); part 0 also takes the boundary rows
+  int split; double* part_out;
+};
+template <class T>
+STAR_GLOBAL void gn_finalize_fused_kernel(const GnFinalizeFusedParams p) {
+  double* red = reinterpret_cast<double*>(dyn_smem());   // [blockDim.x][2]
+  const int t = threadIdx.x, nt = blockDim.x;
+  const int part = (int)(blockIdx.x % (unsigned)p.split), sg = (int)(blockIdx.x / (unsigned)p.split);
+  const int stat = sg >> 5, g = sg & 31;
+  const int cg = p.C >> 5, hp = cg >> 1;                  // channels / channel pairs per group
+  const long long b0 = (long long)stat * p.rows_per_stat, b1 = b0 + p.rows_per_stat;
+  const long long j0 = (b0 + 31) >> 5, j1 = b1 >> 5;      // whole slots [j0, j1)
+  long long head_end = j0 << 5; if (head_end > b1) head_end = b1;
+  long long tail_begin = j1 << 5; if (tail_begin < head_end) tail_begin = head_end;
+  double a = 0.0, b = 0.0;
+  // this part's share [ja, jb) of the whole slots
+  long long ja = j0, jb = j1;
+  if (p.split > 1 && j1 > j0) {
+    const long long per = (j1 - j0 + p.split - 1) / p.split;
+    ja = j0 + per * part; jb = ja + per;
+    if (ja > j1) ja = j1;
+    if (jb > j1) jb = j1;
+  }
+  if (jb > ja) {
+    const long long items = (jb - ja) * hp;
+    const float* base = p.partial + ((size_t)ja * (p.C >> 1) + (size_t)g * hp) * 2;
+    for (long long it = t; it < items; it += nt) {
+      const long long sl = it / hp; const int pr = (int)(it - sl * hp);
+      const vec<float, 2> v = *reinterpret_cast<const vec<float, 2>*>(base + ((size_t)sl * (p.C >> 1) + pr) * 2);
+      a += (double)v[0]; b += (double)v[1];
+    }
+  }
+  if (part == 0) {   // boundary rows [b0, head_end) and [tail_begin, b1), straight from the tensor
+    const long long nh = head_end - b0, ntl = b1 - tail_begin;
+    const T* __restrict__ xg = (const T*)p.x + (size_t)g * cg;
+    for (long long it = t; it < (nh + ntl) * cg; it += nt) {
+      const long long r = it / cg; const int c = (int)(it - r * cg);
+      const long long row = r < nh ? b0 + r : tail_begin + (r - nh);
+      const float f = to_f32<T>(xg[(size_t)row * p.ldx + c]);
+      a += (double)f; b += (double)f * (double)f;
+    }
+  }
+  red[2 * t] = a; red[2 * t + 1] = b;
+  block_sync();
+  for (int st = 1; st < nt; st <<= 1) {   // fixed tree
+    if ((t & (2 * st - 1)) == 0 && t + st < nt) { red[2 * t] += red[2 * (t + st)]; red[2 * t + 1] += red[2 * (t + st) + 1]; }
+    block_sync();
+  }
+  if (p.split > 1) {   // the second stage (gn_finalize_kernel) reduces the parts in order
+    if (t == 0) { p.part_out[2 * (size_t)blockIdx.x] = red[0]; p.part_out[2 * (size_t)blockIdx.x + 1] = red[1]; }
+    return;
+  }
+  const double mean = red[0] / p.count;
+  double var = red[1] / p.count - mean * mean;
+  if (var < 0) var = 0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
+  for (int c = g * cg + t; c < (g + 1) * cg; c += nt) {
+    const float sc = p.gamma[c] * rstd;
+    p.ab[2 * ((size_t)stat * p.C + c)] = sc;
+    p.ab[2 * ((size_t)stat * p.C + c) + 1] = p.beta[c] - (float)mean * sc;
+    if (p.mu) p.mu[(size_t)stat * p.C + c] = (float)mean;
+  }
+}
+
 struct GnApplyParams {
   const void* x; void* y; const float* ab; int ldx, ldy, C; int rows_per_stat; int slab; int silu;
 };

@@ -34,6 +34,11 @@ struct GemmArgs {
   int persist = 0;     // > 0: at most this many workgroups walk the output tiles (multiple of 8); 0 = one workgroup per tile
   int m_off = 0, m_end = 0;   // internal (tail split, gemm_impl.h): this launch covers output rows [m_off, m_end) of the M rows (m_end 0 = M)
   int assume_cus = 0;         // > 0: balance the tile rounds for this many compute units instead of the device's (tests)
+  // GroupNorm statistics in this layer's epilogue (gemm.h EPIF bit 4): gn_partial[ceil(M / 32)][N / 2][2] fp32, written when the tile the
+  // launcher picks has the flavour (256 x 320, 128 x 128 and the scheduled 256 x 256 tile; plain / 3x3 / temporal conv, 16-bit output,
+  // bias (+ residual) epilogue) -- *gn_done says whether it was; otherwise the consumer runs its own statistics pass
+  float* gn_partial = nullptr;
+  bool* gn_done = nullptr;
 };
 int op_gemm(Ctx* ctx, const GemmArgs& a);
 
@@ -75,6 +80,10 @@ int op_temporal_qkv_attn(Ctx* ctx, const TqArgs& a);
 // GroupNorm(32 groups) over channels-last rows; rows_per_stat = H*W (per frame) or F*H*W (whole chunk)
 int op_group_norm(Ctx* ctx, const void* x, int ldx, void* y, int ldy, const float* gamma, const float* beta,
                   int rows, int C, int rows_per_stat, float eps, bool silu);
+// GroupNorm of a tensor whose PRODUCER wrote the partial statistics (GemmArgs::gn_partial): no statistics pass; y == nullptr: the
+// affine pairs only (ab_out [nstat][C][2], mu_out optional [nstat][C])
+int op_group_norm_fused(Ctx* ctx, const void* x, int ldx, void* y, int ldy, const float* gamma, const float* beta, int rows, int C,
+                        int rows_per_stat, float eps, bool silu, const float* partial, float* ab_out = nullptr, float* mu_out = nullptr);
 // statistics + finalize of a GroupNorm only: ab[nstat][C][2] = the per-channel affine pairs (y = x * a + b); nothing is applied;
 // mu (optional) [nstat][C] = the channel's group mean
 int op_group_norm_stats(Ctx* ctx, const void* x, int ldx, const float* gamma, const float* beta, int rows, int C, int rows_per_stat,

@@ -77,6 +77,23 @@ STAR_DEV bf16 from_f32<bf16>(float v) {  // round-to-nearest-even, NaN preserved
   return __builtin_bit_cast(bf16, (uint16_t)(u >> 16));
 }
 
+// fp32 accumulate of a 16-bit pair: c + a.x b.x + a.y b.y (v_dot2_f32_f16 / v_dot2_f32_bf16) and c + a.x + a.y
+template <class T>
+STAR_DEV float dot2_acc(vec<T, 2> a, vec<T, 2> b, float c) {
+#ifndef STAR_HOSTEMU
+  if constexpr (__is_same(T, f16)) return __builtin_amdgcn_fdot2(a, b, c, false);
+  else if constexpr (__is_same(T, bf16)) return __builtin_amdgcn_fdot2_f32_bf16(a, b, c, false);
+  else
+#endif
+  return c + (to_f32<T>(a[0]) * to_f32<T>(b[0]) + to_f32<T>(a[1]) * to_f32<T>(b[1]));
+}
+template <class T>
+STAR_DEV float dot2_one(vec<T, 2> a, float c) {
+  vec<T, 2> one;
+  one[0] = from_f32<T>(1.0f); one[1] = from_f32<T>(1.0f);
+  return dot2_acc<T>(a, one, c);
+}
+
 STAR_DEV int lane_id() {
 #ifdef STAR_HOSTEMU
   return ::star_emu::cur_fiber()->lane;

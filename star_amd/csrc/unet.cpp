@@ -96,7 +96,7 @@ struct Fwd : Runner {
     ok(op_gemv(ctx, emb, r.emb.w.p, (const float*)r.emb.b.p, bias1.as<float>(), r.cout, r.emb.K, true, false));
     ok(op_vec_add_f32(ctx, bias1.as<float>(), (const float*)r.conv1.b.p, r.cout));
     Act h1 = make(r.cout, x.H, x.W);
-    conv3x3(n1, r.conv1, h1, A_CONV3X3, 1, 1, 1, nullptr, bias1.as<float>());
+    conv3x3(n1, r.conv1, h1, A_CONV3X3, 1, 1, 1, nullptr, bias1.as<float>(), 0, nullptr, 0, 1, true);   // + h1's GroupNorm partials (gn2)
     n1.drop();
     Act n2 = make(r.cout, x.H, x.W);
     gn(h1, r.gn2, n2, false, 1e-5f, true);
@@ -109,7 +109,7 @@ struct Fwd : Runner {
       sp = skip.p();
     }
     Act h2 = make(r.cout, x.H, x.W);
-    conv3x3(n2, r.conv2, h2, A_CONV3X3, 1, 1, 1, sp);
+    conv3x3(n2, r.conv2, h2, A_CONV3X3, 1, 1, 1, sp, nullptr, 0, nullptr, 0, 1, true);   // + h2's partials (first temporal GroupNorm)
     n2.drop(); skip.drop(); x.drop();
     // temporal conv block: 4 x [GN(whole chunk) + SiLU + Conv3d(3,1,1)] + identity
     Act cur;  // null => h2
@@ -123,7 +123,7 @@ struct Fwd : Runner {
       g.mode = A_TCONV3; g.Cin = r.cout; g.HW = h2.H * h2.W; g.F = F;
       g.bias = (const float*)r.tconv[k].b.p; g.epi = EPI_BIAS;
       if (k == 3) { g.res = h2.p(); g.ldr = r.cout; g.epi |= EPI_RES; }
-      ok(op_gemm(ctx, g));
+      gemm_to(g, &nxt, k < 3 || want_out_stats);   // partials for the next temporal GroupNorm / for the module behind this block
       cur = std::move(nxt);
     }
     return cur;
@@ -140,7 +140,7 @@ struct Fwd : Runner {
     Act h3 = make(inner, x_in.H, x_in.W);
     gemm(g.p, inner * 4, R, tb.ff2, h3.p(), inner, h2.p(), inner);
     g.reset(); h2.drop();
-    gemm(h3.p(), inner, R, proj_out, out.p(), out.C, x_in.p(), x_in.C);
+    gemm(h3.p(), inner, R, proj_out, out.p(), out.C, x_in.p(), x_in.C, 0, nullptr, want_out_stats ? &out : nullptr);
   }
 
   // SpatialTransformer.forward + BasicTransformerBlock space branch (unet_v2v.py:297-317, 466-477), in two halves:
@@ -226,6 +226,10 @@ struct Fwd : Runner {
     if (fold_gn) {
       Buf ab(ctx, (size_t)C * 2 * 4), mu(ctx, (size_t)C * 4), w2(ctx, (size_t)I * C * es), b2(ctx, (size_t)I * 4);
       if (!ab.p || !mu.p || !w2.p || !b2.p) { rc = ctx->fail("out of device memory (folded GroupNorm)"); return x; }
+      if (x.gnp && x.gnp->p)   // x's producer (the spatial transformer's proj_out) left the partial statistics
+        ok(op_group_norm_fused(ctx, x.p(), x.C, nullptr, 0, (const float*)s.norm.g.p, (const float*)s.norm.b.p, R, C, R, 1e-6f, false, x.gnp->as<float>(),
+                               ab.as<float>(), mu.as<float>()));
+      else
       ok(op_group_norm_stats(ctx, x.p(), x.C, (const float*)s.norm.g.p, (const float*)s.norm.b.p, R, C, R, 1e-6f, ab.as<float>(), mu.as<float>()));
       ok(op_gn_fold_weights(ctx, s.proj_in.w.p, (const float*)s.proj_in.b.p, ab.as<float>(), w2.p, b2.as<float>(), I, C, mu.as<float>()));
       LinW folded; folded.N = I; folded.K = C; folded.w.p = w2.p;
@@ -269,7 +273,7 @@ struct Fwd : Runner {
   Act down(const ConvW& c, Act x) {   // Downsample: conv 3x3 stride 2 padding (2,1) (unet_v2v.py:709-722)
     Act y = make(c.C, x.H / 2 + 1, x.W / 2);
     if ((x.H + 4 - 3) / 2 + 1 != y.H || (x.W + 2 - 3) / 2 + 1 != y.W) { rc = ctx->fail("downsample: illegal latent size"); return y; }
-    conv3x3(x, c.conv, y, A_CONV3X3, 2, 2, 1, nullptr);
+    conv3x3(x, c.conv, y, A_CONV3X3, 2, 2, 1, nullptr, nullptr, 0, nullptr, 0, 1, want_out_stats);
     return y;
   }
   Act up(const ConvW& c, Act x) {     // Upsample: nearest x2, rows [1:-1], conv 3x3 (unet_v2v.py:556-567)
@@ -282,6 +286,20 @@ struct Fwd : Runner {
   // transformer of each net (stem conv, stem temporal transformer, first ResBlock, 28 ms of L0 self-attention ...).
   struct PA { Act a[2]; bool same = true; };
   int nb = 1;
+  // set by the block walker before each module: the module BEHIND this one starts with a GroupNorm of this module's output
+  // (ResBlock in_layers.0, SpatialTransformer.norm, TemporalTransformer.norm, the head's out.0), so the module's last kernel
+  // also writes the output's partial statistics
+  bool want_out_stats = false;
+  // modules of one block in sequence; next_kind: what consumes the block's output (-1: not a GroupNorm, e.g. the decoder's concat)
+  PA run_seq(const Net& net, const std::vector<Mod>& mods, PA x, int next_kind) {
+    for (size_t i = 0; i < mods.size(); ++i) {
+      const int nk = i + 1 < mods.size() ? mods[i + 1].kind : next_kind;
+      want_out_stats = nk == M_RES || nk == M_ST || nk == M_TT;
+      x = run(net, mods[i], std::move(x));
+    }
+    want_out_stats = false;
+    return x;
+  }
   const void* contexts[2] = {nullptr, nullptr};
   PA run(const Net& net, const Mod& m, PA x) {
     PA y;
@@ -567,11 +585,12 @@ static int unet_forward_impl(Ctx* ctx, const float* xt, const float* tsin, const
     PA x = both(x0);
     x0.drop();
     for (size_t bi = 0; bi < net.input_blocks.size(); ++bi) {
-      for (const Mod& m : net.input_blocks[bi]) x = f.run(net, m, std::move(x));
+      const int next_kind = bi + 1 < net.input_blocks.size() ? net.input_blocks[bi + 1][0].kind : net.middle[0].kind;
+      x = f.run_seq(net, net.input_blocks[bi], std::move(x), next_kind);
       if (f.rc) return f.rc;
       control.push_back(lin(x, net.zero_convs[bi]));
     }
-    for (const Mod& m : net.middle) x = f.run(net, m, std::move(x));
+    x = f.run_seq(net, net.middle, std::move(x), -1);
     if (f.rc) return f.rc;
     control.push_back(lin(x, net.middle_out));
   }
@@ -595,11 +614,12 @@ static int unet_forward_impl(Ctx* ctx, const float* xt, const float* tsin, const
     x = both(x0);
   }
   for (size_t bi = 0; bi < net.input_blocks.size(); ++bi) {
-    for (const Mod& m : net.input_blocks[bi]) x = f.run(net, m, std::move(x));
+    const int next_kind = bi + 1 < net.input_blocks.size() ? net.input_blocks[bi + 1][0].kind : net.middle[0].kind;
+    x = f.run_seq(net, net.input_blocks[bi], std::move(x), next_kind);
     if (f.rc) return f.rc;
     xs.push_back(x);   // skip connection shares the buffer(s)
   }
-  for (const Mod& m : net.middle) x = f.run(net, m, std::move(x));
+  x = f.run_seq(net, net.middle, std::move(x), -1);   // (the control residual is added to the middle block's output: its statistics would be stale)
   if (f.rc) return f.rc;
   {
     PA& ctl = control.back();
@@ -625,7 +645,8 @@ static int unet_forward_impl(Ctx* ctx, const float* xt, const float* tsin, const
     if (cat.same) cat.a[1] = cat.a[0];
     xs.pop_back(); control.pop_back();
     x = std::move(cat);
-    for (const Mod& m : net.output_blocks[bi]) x = f.run(net, m, std::move(x));
+    // the last block's output feeds the head's GroupNorm; the others go into the next block's concat
+    x = f.run_seq(net, net.output_blocks[bi], std::move(x), bi + 1 == net.output_blocks.size() ? (int)M_RES : -1);
     if (f.rc) return f.rc;
   }
   // head: GN + SiLU + conv 3x3 -> out_dim, fp32 rows, then back to [1, C, F, H, W]

@@ -113,12 +113,15 @@ class Library:
         self.pool_bytes = _sig(c, "star_pool_bytes", sz, vp)
         self.pool_peak_bytes = _sig(c, "star_pool_peak_bytes", sz, vp)
         self.gemm_split_count = _sig(c, "star_gemm_split_count", i64, vp)
+        self.gn_fused_count = _sig(c, "star_gn_fused_count", i64, vp)
         self.gemm = _sig(c, "star_gemm", i32, vp, ctypes.POINTER(GemmDesc))
+        self.gemm_gn = _sig(c, "star_gemm_gn", i32, vp, ctypes.POINTER(GemmDesc), vp, ctypes.POINTER(ctypes.c_int32))
         f32 = ctypes.c_float
         self.attn_fwd = _sig(c, "star_attn_fwd", i32, vp, ctypes.POINTER(AttnDesc))
         self.temporal_attn_fwd = _sig(c, "star_temporal_attn_fwd", i32, vp, ctypes.POINTER(TAttnDesc))
         self.temporal_qkv_attn = _sig(c, "star_temporal_qkv_attn", i32, vp, ctypes.POINTER(TqDesc))
         self.group_norm = _sig(c, "star_group_norm", i32, vp, vp, i32, vp, i32, vp, vp, i32, i32, i32, f32, i32)
+        self.group_norm_from_partials = _sig(c, "star_group_norm_from_partials", i32, vp, vp, i32, vp, i32, vp, vp, i32, i32, i32, f32, i32, vp)
         self.layer_norm = _sig(c, "star_layer_norm", i32, vp, vp, i32, vp, i32, vp, vp, i32, i32, f32, i32, vp, vp, i32, i32)
         self.layer_norm_rowab = _sig(c, "star_layer_norm_rowab", i32, vp, vp, i32, vp, i32, i32, f32, i32, vp, vp, i32, i32)
         self.concat_add = _sig(c, "star_concat_add", i32, vp, vp, vp, vp, vp, i32, i32, i32)
@@ -241,9 +244,11 @@ class Context:
 
     # ------------------------------------------------------------------ kernels
     def gemm(self, A, W, bias=None, res=None, out=None, *, mode=A_PLAIN, M=None, conv=None, temporal=None,
-             geglu=False, out_f32=False, force_tile=0, up_crop=1, gelu_tanh=False, rowab=None, colsum=None):
+             geglu=False, out_f32=False, force_tile=0, up_crop=1, gelu_tanh=False, rowab=None, colsum=None, gn_partial=False):
         """out[M, N] = epilogue(A' @ W^T).  A: [rows, lda] activations (channels-last tokens);
-        W: [N, K]; conv=(NB,H,Wd,Cin,Ho,Wo,stride,pad_t,pad_l); temporal=(F,HW,Cin)."""
+        W: [N, K]; conv=(NB,H,Wd,Cin,Ho,Wo,stride,pad_t,pad_l); temporal=(F,HW,Cin).
+        gn_partial=True: star_gemm_gn -- returns (out, partial) with partial fp32 [ceil(M/32), N/2, 2] = the GroupNorm partial statistics of
+        out written by the epilogue, or (out, None) when the launcher's tile has no such flavour."""
         self._chk_tensor(A, self.dtype); self._chk_tensor(W, self.dtype)
         self._chk_tensor(bias, torch.float32); self._chk_tensor(res, self.dtype)
         N, K = W.shape
@@ -278,6 +283,11 @@ class Context:
             d.rowab, d.colsum = rowab.data_ptr(), colsum.data_ptr()
             d.epi |= EPI_ROWAFF
         d.force_tile = force_tile
+        if gn_partial:
+            part = torch.empty((M + 31) // 32, N // 2, 2, dtype=torch.float32, device=self.torch_device)
+            wrote = ctypes.c_int32(0)
+            self._check(self.lib.gemm_gn(self.h, ctypes.byref(d), _ptr(part), ctypes.byref(wrote)), "gemm_gn")
+            return out, (part if wrote.value else None)
         self._check(self.lib.gemm(self.h, ctypes.byref(d)), "gemm")
         return out
 
@@ -343,6 +353,18 @@ class Context:
             out = torch.empty(rows, C, dtype=self.dtype, device=self.torch_device)
         self._check(self.lib.group_norm(self.h, _ptr(x), x.stride(0), _ptr(out), out.stride(0), _ptr(gamma), _ptr(beta),
                                         rows, C, rows_per_stat, float(eps), int(silu)), "group_norm")
+        return out
+
+    def group_norm_from_partials(self, x, partial, gamma, beta, rows_per_stat, eps=1e-5, silu=False, out=None):
+        """GroupNorm(32) of x: [rows, C] whose producer wrote `partial` (gemm(..., gn_partial=True)): no statistics pass."""
+        self._chk_tensor(x, self.dtype); self._chk_tensor(gamma, torch.float32); self._chk_tensor(beta, torch.float32)
+        self._chk_tensor(partial, torch.float32)
+        rows, C = x.shape
+        assert tuple(partial.shape) == ((rows + 31) // 32, C // 2, 2)
+        if out is None:
+            out = torch.empty(rows, C, dtype=self.dtype, device=self.torch_device)
+        self._check(self.lib.group_norm_from_partials(self.h, _ptr(x), x.stride(0), _ptr(out), out.stride(0), _ptr(gamma), _ptr(beta),
+                                                      rows, C, rows_per_stat, float(eps), int(silu), _ptr(partial)), "group_norm_from_partials")
         return out
 
     def layer_norm(self, x, gamma, beta, eps=1e-5, mode=LN_PLAIN, gate_w=None, maps=None, H=0, W=0, out=None):

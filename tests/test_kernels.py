@@ -680,3 +680,76 @@ def test_plumbing_kernels(ctx, dtype):
     ref = F.silu(F.silu(xv) @ Wv.float().T + bv)
     assert float((y.cpu() - ref).abs().max()) < 1e-4
     assert torch.equal(ctx.cast(dev(ctx, xv)).cpu(), xv.to(dtype))
+
+
+def _pair_stats(out, M, N):
+    """(sum, sum of squares) of a [M, N] tensor per 32-row slot and channel pair, in float64 -> [ceil(M/32), N/2, 2]"""
+    o = out.double().cpu()
+    pad = (-M) % 32
+    if pad:
+        o = torch.cat([o, torch.zeros(pad, N, dtype=torch.float64)])
+    o = o.reshape(-1, 32, N // 2, 2)
+    return torch.stack([o.sum(dim=(1, 3)), (o * o).sum(dim=(1, 3))], dim=-1)
+
+
+GN_EPI_CASES = [   # mode, tile, (frames, H, W), Cin, Cout, residual
+    ("plain", 2, (3, 11, 9), 192, 320, True),      # proj_out + x_in (SpatialTransformer -> TemporalTransformer.norm), 256 x 320 tile: 3 rows x 20 chunk columns per pass
+    ("plain", 3, (3, 11, 9), 128, 192, True),      # 128 x 128 tile (the tail-split remainder), ragged last column tile
+    ("plain", 17, (2, 17, 16), 128, 256, False),   # scheduled one-wave-per-SIMD tile
+    ("conv", 2, (3, 11, 9), 64, 320, False),       # ResBlock conv1 -> out_layers.0 (per-frame statistics: 99 rows per frame cut the 32-row slots)
+    ("conv", 3, (2, 10, 8), 64, 128, True),        # conv2 + skip
+    ("conv", 17, (2, 17, 16), 64, 256, False),
+    ("tconv", 2, (5, 7, 9), 320, 320, True),       # TemporalConvBlock_v2 conv4 + identity
+    ("tconv", 3, (4, 6, 8), 64, 64, False),
+    ("plain", 3, (4, 64, 50), 64, 64, True),       # 12 800 rows: the whole-chunk finalize is split into parts along the slots (two-stage reduction)
+]
+
+
+@pytest.mark.parametrize("mode,tile,geom,Cin,Cout,with_res", GN_EPI_CASES)
+def test_group_norm_statistics_in_the_producer_epilogue(ctx, dtype, mode, tile, geom, Cin, Cout, with_res):
+    """star_gemm_gn + star_group_norm_from_partials (gemm.h EPIF bit 4, norm.h gn_finalize_fused_kernel; unet_v2v.py:609-640,1209-1220):
+    the layer's output is bit-identical to star_gemm's; the partials are the sums of the STORED outputs per 32-row slot and channel
+    pair; the GroupNorm finalized from them (per-frame statistics whose boundaries cut the slots, and whole-chunk statistics) matches
+    torch's on the stored tensor as closely as the stand-alone kernel does."""
+    Fr, H, Wd = geom
+    g = torch.Generator().manual_seed(Cin + Cout + tile)
+    M = Fr * H * Wd
+    res = dev(ctx, (torch.randn(M, Cout, generator=g) * 0.7 + 0.3).to(dtype)) if with_res else None
+    b = dev(ctx, torch.randn(Cout, generator=g))
+    if mode == "plain":
+        a = dev(ctx, torch.randn(M, Cin, generator=g).to(dtype))
+        w = dev(ctx, (torch.randn(Cout, Cin, generator=g) / math.sqrt(Cin)).to(dtype))
+        kw = dict(mode=L.A_PLAIN)
+    elif mode == "conv":
+        x = torch.randn(Fr, Cin, H, Wd, generator=g).to(dtype)
+        a = dev(ctx, nhwc_rows(x))
+        w = dev(ctx, (torch.randn(Cout, 9 * Cin, generator=g) / math.sqrt(9 * Cin)).to(dtype))
+        kw = dict(mode=L.A_CONV3X3, conv=(Fr, H, Wd, Cin, H, Wd, 1, 1, 1))
+    else:
+        a = dev(ctx, torch.randn(M, Cin, generator=g).to(dtype))
+        w = dev(ctx, (torch.randn(Cout, 3 * Cin, generator=g) / math.sqrt(3 * Cin)).to(dtype))
+        kw = dict(mode=L.A_TCONV3, temporal=(Fr, H * Wd, Cin))
+    plain = ctx.gemm(a, w, bias=b, res=res, force_tile=tile, **kw)
+    out, part = ctx.gemm(a, w, bias=b, res=res, force_tile=tile, gn_partial=True, **kw)
+    assert part is not None, "the tile has the statistics flavour"
+    assert torch.equal(out, plain)
+    want = _pair_stats(out, M, Cout)
+    got = part.double().cpu()
+    scale = want[..., 1].abs().max().item() + 1.0
+    assert (got - want).abs().max().item() <= 2e-5 * scale, (got - want).abs().max().item()
+    if Cout % 64:
+        return   # GroupNorm(32) needs an even number of channels per group for the pair partials
+    gam, bet = torch.randn(Cout, generator=g), torch.randn(Cout, generator=g)
+    for rps, eps, silu in ((H * Wd, 1e-5, True), (M, 1e-6, False)):
+        y = ctx.group_norm_from_partials(out, part, dev(ctx, gam), dev(ctx, bet), rps, eps=eps, silu=silu)
+        y0 = ctx.group_norm(out, dev(ctx, gam), dev(ctx, bet), rps, eps=eps, silu=silu)
+        xr = out.float().cpu().reshape(-1, rps, Cout).permute(0, 2, 1)
+        ref = F.group_norm(xr, 32, gam, bet, eps)
+        if silu:
+            ref = F.silu(ref)
+        ref = ref.permute(0, 2, 1).reshape(-1, Cout)
+        assert_close(y, ref, dtype, what=f"gn from partials rps={rps}")
+        assert (y.float() - y0.float()).abs().max().item() <= (2e-2 if dtype == torch.bfloat16 else 4e-3) * (1 + ref.abs().max().item())
+    # a tile without the flavour: the output is still computed, no partials
+    out4, part4 = ctx.gemm(a, w, bias=b, res=res, force_tile=4 if mode == "plain" else 1, gn_partial=True, **kw)
+    assert part4 is None and out4.shape == out.shape

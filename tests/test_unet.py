@@ -239,10 +239,31 @@ def test_group_norm_fold_with_large_group_means(backend, dtype, request):
     gmean = (10.0 + 30.0 * torch.rand(32, generator=g)) * (torch.randint(0, 2, (32,), generator=g) * 2 - 1)
     x = 0.03 * (gmean.repeat_interleave(C // 32)[None, :, None, None] + torch.randn(b["x"].shape, generator=g))
     x = x.to(dtype).float()                                  # exactly representable: the input rounding is not what is measured
-    y = run_module(ctx, "tt", sd, "m", x, heads=2, cout=C)
+    y = run_module(ctx, "tt", sd, "m", x, heads=2, cout=C).cpu()
     ref = O.temporal_transformer({"m." + k: v for k, v in sd.items()}, "m", x.permute(1, 0, 2, 3)[None], 2)[0].permute(1, 0, 2, 3)
     branch, rbranch = y - x, ref - x
     assert float(rbranch.abs().mean()) > 10 * float(x.abs().mean()) * 2.0 ** (-8 if dtype == torch.bfloat16 else -11)   # the branch is not lost in the residual's rounding
     e = rel_rms(branch, rbranch)
     assert e < (6e-3 if dtype == torch.float16 else 5e-2), e
     ctx.close()
+
+
+def test_forward_takes_group_norm_statistics_from_the_producers(backend, request):
+    """In a forward, the GroupNorms behind a conv / temporal conv / proj_out (ResBlock out_layers.0, the four temporal norms, the
+    transformers' input norms, the next block's in_layers.0; unet_v2v.py:609-640,1002,1209-1220) are finalized from the partial
+    statistics their producer's epilogue wrote (star_gn_fused_count), the others (after a concat, after the stem) run their own pass;
+    the result matches the reference golden like the stand-alone path (tests above run with the fused path on)."""
+    net = _small_model(backend, torch.float16, request)
+    gold = torch.load(os.path.join(GOLD, "unet_small_f4_10x8.pt"))
+    f, h, w, seed = gold["case"]
+    x, t, y, hint = unet_inputs(SMALL_TEST_CONFIG, f, h, w, seed)
+    dev = net.ctx.torch_device
+    n0 = net.ctx.lib.gn_fused_count(net.ctx.h)
+    out = net(x.to(dev), t=t, y=y.to(dev), hint=hint.to(dev))
+    fused = net.ctx.lib.gn_fused_count(net.ctx.h) - n0
+    assert rel_rms(out, gold["out"]) < REL_RMS[torch.float16][1]
+    if os.environ.get("STAR_NO_GNEPI"):
+        assert fused == 0
+    else:
+        # per ResBlock: out_layers.0 + 4 temporal norms = 5 fused (38 blocks in the two nets), plus the transformer / next-block norms
+        assert fused >= 5 * 38, fused

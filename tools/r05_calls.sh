@@ -1,0 +1,45 @@
+#!/bin/bash
+# Round-5 GPU calls: each block is ONE gpurun call; run from the
+# repo root on the GPU box (gpurun -- 'bash tools/r05_calls.sh 1').  Outputs under gpurun_out/ (copy what is quoted into profiles/).
+set -u
+mkdir -p gpurun_out
+case "${1:-1}" in
+  1)  # MFMA shadow: the other instruction kinds of the K / key loops, and two waves per SIMD
+      timeout 60 ./tools/probe/mfma_valu_overlap 20000 1 > gpurun_out/r05_probe_mfma_valu_overlap2.txt 2>&1
+      tail -5 gpurun_out/r05_probe_mfma_valu_overlap2.txt ;;
+  2)  # what the A-stationary kernel waits for: PMC passes on a torch-free run (counters in their own runs, kernel trace only)
+      cd /tmp && export TMPDIR=/tmp
+      R=${GRAFT_REPO_ROOT:-/root/repo}
+      printf 'gemm 843264 2560 320 37 30\ngemm 843264 960 320 33 30\n' > /tmp/astat.txt
+      for pmc in "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES" "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_WAVE_CYCLES" \
+                 "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES"; do
+        tag=$(echo "$pmc" | cut -d' ' -f1)
+        timeout 120 rocprofv3 --kernel-trace --pmc $pmc -d $R/gpurun_out/r05_pmc_astat_$tag -- \
+          $R/tools/cbench/cbench $R/tools/bench/libstar_hip_bench.so f16 /tmp/astat.txt 2 > $R/gpurun_out/r05_pmc_astat_$tag.log 2>&1
+      done
+      ls $R/gpurun_out | tail ;;
+  4)  # A-stationary kernel without its global stores (hypothesis: in-order vmcnt couples the W-tile wait to the stores' latency)
+      timeout 60 ./tools/cbench/cbench tools/bench/libstar_hip_bench.so f16 tools/cbench/astat_nostore.txt 8 > gpurun_out/r05_cbench_astat_nostore.txt 2>&1
+      cat gpurun_out/r05_cbench_astat_nostore.txt ;;
+  3)  # the tile sweep on the current tree (21 s)
+      timeout 90 ./tools/cbench/cbench tools/bench/libstar_hip_bench.so f16 tools/cbench/cfg2_tile_sweep.txt 6 > gpurun_out/r05_cbench_tile_sweep.txt 2>&1
+      tail -5 gpurun_out/r05_cbench_tile_sweep.txt ;;
+  5)  # A-stationary product (nt stores + staggered start) against the round-4 kernel; the new GPU tests; forward A/B of the GroupNorm
+      # statistics in the producers' epilogues (same box, same process order)
+      timeout 60 ./tools/cbench/cbench tools/bench/libstar_hip_bench.so f16 tools/cbench/astat_product.txt 8 > gpurun_out/r05_cbench_astat_product.txt 2>&1
+      cat gpurun_out/r05_cbench_astat_product.txt
+      timeout 900 python -m pytest tests/test_kernels.py tests/test_unet.py tests/test_parity_cfg4.py -m gpu -x -q -k "producer_epilogue or statistics_from or large_group_means or cfg4 or blocks_match or small_unet or gemm_folded or persistent_tile" 2>&1 | tail -15 > gpurun_out/r05_pytest_gpu_new.txt
+      cat gpurun_out/r05_pytest_gpu_new.txt
+      ( timeout 400 python tools/profile_forward.py 2>&1 | grep -v amdgpu.ids ) > gpurun_out/r05_forward_detail_f16_gnepi.txt 2>&1
+      ( STAR_NO_GNEPI=1 timeout 400 python tools/profile_forward.py 2>&1 | grep -v amdgpu.ids ) > gpurun_out/r05_forward_detail_f16_nognepi.txt 2>&1
+      head -3 gpurun_out/r05_forward_detail_f16_gnepi.txt; grep group_norm gpurun_out/r05_forward_detail_f16_gnepi.txt | head -3
+      head -3 gpurun_out/r05_forward_detail_f16_nognepi.txt; grep group_norm gpurun_out/r05_forward_detail_f16_nognepi.txt | head -3 ;;
+  6)  # GroupNorm family after the split finalize: forward table + per-kernel rocprof stats of the same forward
+      timeout 600 python -m pytest tests/test_kernels.py tests/test_unet.py -m gpu -x -q -k "producer_epilogue or statistics_from or large_group_means" 2>&1 | tail -5 > gpurun_out/r05_pytest_gpu_new2.txt
+      cat gpurun_out/r05_pytest_gpu_new2.txt
+      ( timeout 400 python tools/profile_forward.py 2>&1 | grep -v amdgpu.ids ) > gpurun_out/r05_forward_detail_f16_gnepi2.txt 2>&1
+      head -3 gpurun_out/r05_forward_detail_f16_gnepi2.txt; grep group_norm gpurun_out/r05_forward_detail_f16_gnepi2.txt | head -3
+      R=${GRAFT_REPO_ROOT:-/root/repo}; cd /tmp && export TMPDIR=/tmp
+      timeout 500 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/r05_prof_fwd -o fwd -- python $R/tools/profile_forward.py --reps 1 > $R/gpurun_out/r05_prof_fwd.log 2>&1
+      ls $R/gpurun_out/r05_prof_fwd* | head ;;
+esac
