@@ -133,21 +133,36 @@ def attention_operand_sweep(ctx, dev, device_index, heads=5, frames=32, hw=(122,
     out = torch.empty(frames, N, C, device=dev, dtype=ctx.dtype)
     flops = 4.0 * frames * heads * float(N) * N * 64
     res = {}
-    for name, qkv in sets.items():
-        fn = lambda: ctx.attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], heads, out=out)
-        fn(); ctx.sync(); torch.cuda.synchronize()
+    runs = [(name, ctx, 9, qkv) for name, qkv in sets.items()]
+    # the SAME kernel without its softmax VALU (QK^T, P V, LDS reads, staging and barriers kept; P is a constant: "variant 16", a timing
+    # ablation that exists in the bench build of the library only) on the N(0,1) operands, in this very run: the MFMA + staging skeleton's
+    # power-bound rate on this socket = the ceiling any softmax placement could reach on this data
+    bench_so = os.path.join(ROOT, "tools", "bench", "libstar_hip_bench.so")
+    bctx = None
+    if os.path.isfile(bench_so):
+        try:
+            from star_amd import lib as L_
+            bctx = L_.Context(device_index, ctx.dtype, L_.Library(bench_so))
+            runs.append(("mfma_skeleton_no_softmax_normal", bctx, 16, sets["normal"]))
+        except Exception as e:   # measurement tooling only: the bench line does not depend on it
+            print(f"bench: skeleton ceiling not measured ({e})", file=sys.stderr)
+    for name, c_, variant, qkv in runs:
+        fn = lambda: c_.attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], heads, out=out, variant=variant)
+        fn(); c_.sync(); torch.cuda.synchronize()
         ps = PowerSampler(device_index, 0.05).start()
         n, t0 = 0, time.perf_counter()
         while time.perf_counter() - t0 < seconds:      # 10 launches (~0.25 s) per host synchronisation: the wall clock is the kernel time
             for _ in range(10):
                 fn()
-            ctx.sync(); torch.cuda.synchronize(); n += 10
+            c_.sync(); torch.cuda.synchronize(); n += 10
         ms = (time.perf_counter() - t0) * 1e3 / n
         ps.stop()
         pw = ps.summary(skip=0.5)
         res[name] = {"ms": round(ms, 3), "TFLOP/s": round(flops / ms / 1e9, 1), "frac_of_peak": round(flops / ms / 1e9 / (PEAK_BF16_MFMA / 1e12), 4),
                      "socket_W": pw["socket_W"]["mean"] if pw else None, "sclk_MHz": pw["sclk_MHz"]["mean"] if pw else None, "launches": n}
     del sets, pk, out
+    if bctx is not None:
+        bctx.close()
     return res
 
 
@@ -338,8 +353,21 @@ def main():
             roof["second_operating_point"] = {"operands": "trained-like peaked logits (tests/test_fullsize.py statistics) -- NOT the headline: the clip's own "
                                                           "operands are the N(0,1)-like activations of random-init weights",
                                               "achieved": pk_["TFLOP/s"], "frac": pk_["frac_of_peak"], "socket_W": pk_["socket_W"], "sclk_MHz": pk_["sclk_MHz"]}
-        roof["mfma_skeleton_ceiling_on_random_operands"] = {"TFLOP/s": 1568.0, "source": "static: profiles/r02_power_limit.txt (variant 16, N(0,1) f16), a round-2 measurement, not re-measured in this run",
-                                                            "frac_of_it": roof["achieved"] / 1568.0 if roof["achieved"] else None}
+        skel = sweep.pop("mfma_skeleton_no_softmax_normal", None) if sweep else None
+        if skel:   # measured in THIS run, beside the operand sweep (bench build of the library, variant 16)
+            roof["mfma_skeleton_ceiling_on_random_operands"] = {"TFLOP/s": skel["TFLOP/s"], "socket_W": skel["socket_W"], "sclk_MHz": skel["sclk_MHz"],
+                "source": "live: flash_attn_v3_kernel<..., ABL 5> (variant 16 of tools/bench/libstar_hip_bench.so: the kernel without its softmax VALU) looped on the "
+                          "N(0,1) operand set right after the timed region, hwmon sampled beside it",
+                "frac_of_nominal": skel["frac_of_peak"]}
+            ceil_tf = skel["TFLOP/s"]
+        else:
+            roof["mfma_skeleton_ceiling_on_random_operands"] = {"TFLOP/s": 1568.0, "source": "static: profiles/r02_power_limit.txt (variant 16, N(0,1) f16), a round-2 "
+                                                                "measurement -- the bench build of the library was not found / not loadable in this run"}
+            ceil_tf = 1568.0
+        # what the kernel reaches of the power-bound ceiling of its own MFMA + staging skeleton on the same data, socket and run; the 0.70 of the
+        # NOMINAL peak that north_star names lies above that ceiling
+        roof["power_ceiling_frac"] = roof["achieved"] / ceil_tf if roof["achieved"] else None
+        roof["power_ceiling_frac_same_operands_alone"] = (sweep["normal"]["TFLOP/s"] / ceil_tf) if sweep and sweep.get("normal") else None
         breakdown = None if prof_u_all is None else {k: {"ms": round(v["ms"], 1), "launches": v["launches"],
                          "TFLOP/s": round(v["flops"] / v["ms"] / 1e9, 1) if v["ms"] and v["flops"] else None,
                          "GB/s": round(v["bytes"] / v["ms"] / 1e6, 1) if v["ms"] else None} for k, v in prof_u_all.items()}

@@ -42,4 +42,16 @@ case "${1:-1}" in
       R=${GRAFT_REPO_ROOT:-/root/repo}; cd /tmp && export TMPDIR=/tmp
       timeout 500 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/r05_prof_fwd -o fwd -- python $R/tools/profile_forward.py --reps 1 > $R/gpurun_out/r05_prof_fwd.log 2>&1
       ls $R/gpurun_out/r05_prof_fwd* | head ;;
+  7)  # checkpoint: the whole GPU suite + smoke + a short bench line (1 warm-up clip with the per-family table, 2 timed clips)
+      ( time timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -15 ) > gpurun_out/r05_pytest_gpu_v1.txt 2>&1
+      tail -8 gpurun_out/r05_pytest_gpu_v1.txt
+      timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+      timeout 900 python bench.py --steps 2 --warmup 1 > gpurun_out/r05_bench_v1_f16_n1.json 2> gpurun_out/r05_bench_v1.err
+      tail -c 600 gpurun_out/r05_bench_v1.err; python - <<'PY'
+import json
+d = json.loads(open('gpurun_out/r05_bench_v1_f16_n1.json').read().strip().split('\n')[-1])
+print({k: d[k] for k in ('value', 'ms_per_step')}, {k: d['roofline'].get(k) for k in ('achieved', 'frac', 'power_ceiling_frac')}, d['roofline'].get('mfma_skeleton_ceiling_on_random_operands', {}).get('TFLOP/s'))
+print(d.get('unet_kernel_ms') or d.get('breakdown'))
+PY
+      ;;
 esac
