@@ -713,6 +713,8 @@ gemm_kernel(const GemmParams p) {
           for (int e = 0; e < 8; ++e) ov[e] = from_f32<T>(to_f32<T>(ov[e]) + to_f32<T>(rv[i][u][e]));
         }
         if (act && m < p.M && n < N_out && (ABL != 5 || p.M < 0)) {
+          // (non-temporal stores here are neutral, +-0.5 % on every level-0 shape: profiles/r05_cbench_gemm_nt.txt -- unlike the
+          // A-stationary kernel, whose W panel lives in the L2 for the whole launch)
           *reinterpret_cast<vec<T, 8>*>((T*)p.C + (size_t)m * p.ldc + n) = ov;
           if constexpr (STATS) {
 #pragma unroll

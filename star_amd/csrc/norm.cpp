@@ -150,9 +150,21 @@ int op_layer_norm(Ctx* ctx, const void* x, int ldx, void* y, int ldy, const floa
   return ln_t<bf16>(ctx, p);
 }
 
-int op_concat_add(Ctx* ctx, const void* a, const void* b, const void* c, void* out, int rows, int C1, int C2) {
+int op_concat_add(Ctx* ctx, const void* a, const void* b, const void* c, void* out, int rows, int C1, int C2, float* gn_partial) {
   ProfScope ps(ctx, PK_MISC, 0.0, 2.0 * rows * (double)(C1 + C2 + (c ? C2 : 0)) * 2.0);
   if ((C1 | C2) & 7) return ctx->fail("concat_add: channel counts must be multiples of 8");
+  if (gn_partial) {   // + the GroupNorm partial statistics of the output (one workgroup per 32-row slot)
+    const int CT8 = (C1 + C2) / 8;
+    if (CT8 > 1024) return ctx->fail("concat_add: too many channels for the statistics form");
+    int RL = 256 / CT8; if (RL < 1) RL = 1;
+    if (RL > 32) RL = 32;
+    ConcatStatsParams sp{a, b, c, out, C1, C2, rows, gn_partial};
+    const dim3 grid((unsigned)((rows + 31) / 32)), block((unsigned)(CT8 * RL));
+    const size_t smem = (size_t)CT8 * RL * 8 * sizeof(float);
+    if (ctx->dtype == DT_F16) STAR_LAUNCH((concat_add_stats_kernel<f16>), grid, block, smem, ctx->stream, sp);
+    else STAR_LAUNCH((concat_add_stats_kernel<bf16>), grid, block, smem, ctx->stream, sp);
+    return 0;
+  }
   ConcatParams p{a, b, c, out, C1, C2, rows};
   const unsigned g = ew_grid((long long)rows * ((C1 + C2) / 8));
   if (ctx->dtype == DT_F16) STAR_LAUNCH((concat_add_kernel<f16>), dim3(g), dim3(256), (size_t)0, ctx->stream, p);

@@ -408,6 +408,64 @@ STAR_GLOBAL void concat_add_kernel(const ConcatParams p) {
   }
 }
 
+// The same concat, ALSO writing the GroupNorm partial statistics of its output (the decoder's in_layers.0 reads it next,
+// unet_v2v.py:1792,609-612) in the layout of the GEMM epilogues (gemm.h EPIF bit 4: [ceil(rows / 32)][C / 2][2], sum and sum of squares
+// of the stored values per 32-row slot and channel pair).  One workgroup per slot: thread (rl, cc) owns the 8-channel chunk column cc and
+// walks the rows rl, rl + RL, ...; the RL row lanes of a column meet in LDS and are added in order (deterministic).
+struct ConcatStatsParams { const void* a; const void* b; const void* c; void* out; int C1, C2, rows; float* partial; };
+template <class T>
+STAR_GLOBAL void concat_add_stats_kernel(const ConcatStatsParams p) {
+  float* red = reinterpret_cast<float*>(dyn_smem());   // [RL][CT8][8]
+  const int CT = p.C1 + p.C2, CT8 = CT >> 3, C18 = p.C1 >> 3;
+  const int t = threadIdx.x;
+  const int RL = blockDim.x / CT8;
+  const int cc = t % CT8, rl = t / CT8;
+  const int r0 = blockIdx.x * 32;
+  int r1 = r0 + 32;
+  if (r1 > p.rows) r1 = p.rows;
+  float ps[4], pq[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { ps[e] = 0.f; pq[e] = 0.f; }
+  if (rl < RL) {
+    for (int row = r0 + rl; row < r1; row += RL) {
+      vec<T, 8> o;
+      if (cc < C18) {
+        o = *reinterpret_cast<const vec<T, 8>*>((const T*)p.a + (size_t)row * p.C1 + cc * 8);
+      } else {
+        const size_t off = (size_t)row * p.C2 + (cc - C18) * 8;
+        o = *reinterpret_cast<const vec<T, 8>*>((const T*)p.b + off);
+        if (p.c) {
+          const vec<T, 8> c = *reinterpret_cast<const vec<T, 8>*>((const T*)p.c + off);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = from_f32<T>(to_f32<T>(o[e]) + to_f32<T>(c[e]));
+        }
+      }
+      *reinterpret_cast<vec<T, 8>*>((T*)p.out + (size_t)row * CT + cc * 8) = o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        vec<T, 2> pr;
+        pr[0] = o[2 * e]; pr[1] = o[2 * e + 1];
+        ps[e] = dot2_one<T>(pr, ps[e]);
+        pq[e] = dot2_acc<T>(pr, pr, pq[e]);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[(rl * CT8 + cc) * 8 + 2 * e] = ps[e]; red[(rl * CT8 + cc) * 8 + 2 * e + 1] = pq[e]; }
+  }
+  block_sync();
+  if (rl == 0) {
+    f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+    for (int l = 0; l < RL; ++l) {
+      const float* q = red + (l * CT8 + cc) * 8;
+      lo += *reinterpret_cast<const f32x4*>(q);
+      hi += *reinterpret_cast<const f32x4*>(q + 4);
+    }
+    float* dst = p.partial + (size_t)blockIdx.x * CT + cc * 8;
+    *reinterpret_cast<f32x4*>(dst) = lo;
+    *reinterpret_cast<f32x4*>(dst + 4) = hi;
+  }
+}
+
 // out = a + b (same shape, n multiple of 8)
 struct AddParams { const void* a; const void* b; void* out; long long n8; };
 template <class T>

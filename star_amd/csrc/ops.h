@@ -94,7 +94,8 @@ int op_gn_fold_weights(Ctx* ctx, const void* W, const float* bias, const float* 
                        const float* mu = nullptr);
 int op_layer_norm(Ctx* ctx, const void* x, int ldx, void* y, int ldy, const float* gamma, const float* beta,
                   int rows, int C, float eps, int mode, const float* gate_w, float* maps, int H, int W, float* rowab = nullptr);
-int op_concat_add(Ctx* ctx, const void* a, const void* b, const void* c, void* out, int rows, int C1, int C2);
+// gn_partial (optional): also write the output's GroupNorm partial statistics [ceil(rows / 32)][(C1 + C2) / 2][2] (GemmArgs::gn_partial layout)
+int op_concat_add(Ctx* ctx, const void* a, const void* b, const void* c, void* out, int rows, int C1, int C2, float* gn_partial = nullptr);
 int op_add(Ctx* ctx, const void* a, const void* b, void* out, long long n);
 int op_stem_im2col(Ctx* ctx, const float* latent, void* out, int Cl, int F, int H, int W, bool frame_major = false);
 int op_softmax_rows(Ctx* ctx, const float* s, int lds, void* pout, int ldp, int rows, int n, float scale);

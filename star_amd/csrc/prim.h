@@ -77,6 +77,15 @@ STAR_DEV bf16 from_f32<bf16>(float v) {  // round-to-nearest-even, NaN preserved
   return __builtin_bit_cast(bf16, (uint16_t)(u >> 16));
 }
 
+// 16-byte global store that does not allocate in the L2 (global_store_dwordx4 ... nt)
+template <class V>
+STAR_DEV void store_nt(V* dst, V v) {
+#ifdef STAR_HOSTEMU
+  *dst = v;
+#else
+  __builtin_nontemporal_store(v, dst);
+#endif
+}
 // fp32 accumulate of a 16-bit pair: c + a.x b.x + a.y b.y (v_dot2_f32_f16 / v_dot2_f32_bf16) and c + a.x + a.y
 template <class T>
 STAR_DEV float dot2_acc(vec<T, 2> a, vec<T, 2> b, float c) {

@@ -640,7 +640,14 @@ static int unet_forward_impl(Ctx* ctx, const float* xt, const float* tsin, const
     for (int b = 0; b < (cat.same ? 1 : nb); ++b) {
       if (skip.a[b].H != x.a[b].H || skip.a[b].W != x.a[b].W) return ctx->fail("unet_forward: skip shape mismatch");
       cat.a[b] = f.make(x.a[b].C + skip.a[b].C, x.a[b].H, x.a[b].W);
-      f.ok(op_concat_add(ctx, x.a[b].p(), skip.a[b].p(), ctl.a[b].p(), cat.a[b].p(), f.rows(x.a[b]), x.a[b].C, skip.a[b].C));
+      // the block behind it starts with a GroupNorm of the concatenation (in_layers.0): the concat writes its partial statistics
+      std::shared_ptr<Buf> part;
+      if (Fwd::gn_epi_enabled() && !((x.a[b].C + skip.a[b].C) & 63)) {
+        part = std::make_shared<Buf>(ctx, (size_t)((f.rows(x.a[b]) + 31) / 32) * (x.a[b].C + skip.a[b].C) * sizeof(float));
+        if (!part->p) part.reset();
+      }
+      f.ok(op_concat_add(ctx, x.a[b].p(), skip.a[b].p(), ctl.a[b].p(), cat.a[b].p(), f.rows(x.a[b]), x.a[b].C, skip.a[b].C, part ? part->as<float>() : nullptr));
+      cat.a[b].gnp = part;
     }
     if (cat.same) cat.a[1] = cat.a[0];
     xs.pop_back(); control.pop_back();

@@ -265,5 +265,5 @@ def test_forward_takes_group_norm_statistics_from_the_producers(backend, request
     if os.environ.get("STAR_NO_GNEPI"):
         assert fused == 0
     else:
-        # per ResBlock: out_layers.0 + 4 temporal norms = 5 fused (38 blocks in the two nets), plus the transformer / next-block norms
-        assert fused >= 5 * 38, fused
+        # every ResBlock: out_layers.0 + 4 temporal norms; the transformers' input norms; in_layers.0 behind a block or a concat
+        assert fused >= 235, fused   # measured: 239 of the 266 GroupNorms of a forward (the rest follow the stem, an Upsample or the middle add)
