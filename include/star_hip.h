@@ -58,6 +58,8 @@ int64_t star_gemm_split_count(star_ctx* ctx);
 /* diagnostic: how many GroupNorms of this context were finalized from their producer's partial statistics (star_gemm_gn / the
  * forward's conv, temporal-conv and proj_out epilogues) instead of running a statistics pass over their input */
 int64_t star_gn_fused_count(star_ctx* ctx);
+/* ... and how many LayerNorm row-coefficient / LIEM-map passes were served from their producer's row statistics (star_gemm_rowstats) */
+int64_t star_ln_fused_count(star_ctx* ctx);
 
 /* ---- kernel-level entry points (unit parity; each is one HIP kernel family) */
 typedef struct star_gemm_desc {
@@ -87,6 +89,13 @@ int star_gemm(star_ctx* ctx, const star_gemm_desc* d);
  * plain / 3x3 / temporal-conv layers with the bias (+ residual) 16-bit epilogue; *wrote = 1 if the partials were written, 0 if the launcher's
  * tile has no such flavour (the output is computed either way). */
 int star_gemm_gn(star_ctx* ctx, const star_gemm_desc* d, float* gn_partial, int32_t* wrote);
+/* star_gemm whose epilogue ALSO writes per-ROW statistics of its output -- what the projections in front of an nn.LayerNorm do in the
+ * forward (unet_v2v.py:448-450,466-490: proj_in / to_out + residual -> norm1 / norm2 / norm3 and the LIEM gates), so that the norm's row
+ * coefficients need no pass over the rows.  ln_partial: fp32 [M][parts][4] = (sum, sum of squares, max, 0) of the STORED 16-bit outputs
+ * of row m over the columns of one part; the buffer holds parts_cap parts per row, *parts receives the number written (2 per 320-column
+ * tile of the 256 x 320 tile, 2 per 128-column tile of the 128 x 128 tile).  Plain-A layers with the bias (+ residual) 16-bit epilogue;
+ * *wrote = 0 (and nothing is written) when the launcher's tile has no such flavour or parts_cap is too small. */
+int star_gemm_rowstats(star_ctx* ctx, const star_gemm_desc* d, float* ln_partial, int32_t parts_cap, int32_t* parts, int32_t* wrote);
 
 
 /* replaces: xformers.ops.memory_efficient_attention(q,k,v) for spatial self- and text cross-attention
@@ -147,6 +156,10 @@ int star_layer_norm(star_ctx* ctx, const void* x, int32_t ldx, void* y, int32_t 
  * colsum[n] = sum_k W'[n][k], bias'[n] = sum_k beta[k] W[n][k] + bias[n] (prepared once per layer by the caller). */
 int star_layer_norm_rowab(star_ctx* ctx, const void* x, int32_t ldx, float* rowab, int32_t rows, int32_t C, float eps, int32_t mode,
                           const float* gate_w, float* maps, int32_t H, int32_t W);
+/* star_layer_norm_rowab (or, with mode 3, the LIEM maps of star_layer_norm) from the row statistics the producer of x wrote
+ * (star_gemm_rowstats): 16 x parts bytes are read per row instead of the row.  mode 3: maps[row] = (max, mean), rowab unused. */
+int star_layer_norm_rowab_from_partials(star_ctx* ctx, const float* ln_partial, int32_t parts, float* rowab, int32_t rows, int32_t C,
+                                        float eps, int32_t mode, const float* gate_w, float* maps, int32_t H, int32_t W);
 /* replaces: torch.cat([x, skip + control], dim=1) (unet_v2v.py:1792) and residual adds */
 int star_concat_add(star_ctx* ctx, const void* a, const void* b, const void* c, void* out, int32_t rows, int32_t C1, int32_t C2);
 int star_add(star_ctx* ctx, const void* a, const void* b, void* out, int64_t n);

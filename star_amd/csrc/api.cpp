@@ -118,11 +118,14 @@ size_t star_pool_bytes(star_ctx* h) { return h->c.pool.total(); }
 size_t star_pool_peak_bytes(star_ctx* h) { return h->c.pool.peak(); }
 int64_t star_gemm_split_count(star_ctx* h) { return h ? (int64_t)h->c.gemm_splits : 0; }
 int64_t star_gn_fused_count(star_ctx* h) { return h ? (int64_t)h->c.gn_fused : 0; }
+int64_t star_ln_fused_count(star_ctx* h) { return h ? (int64_t)h->c.ln_fused : 0; }
 
-static int gemm_from_desc(star_ctx* h, const star_gemm_desc* d, float* gn_partial, bool* gn_done) {
+static int gemm_from_desc(star_ctx* h, const star_gemm_desc* d, float* gn_partial, bool* gn_done, float* ln_partial = nullptr, int ln_cap = 0,
+                          int* ln_parts = nullptr, bool* ln_done = nullptr) {
   if (h) rt::set_device(h->c.device);   // follow the context's device, not the caller's current one
   GemmArgs a;
   a.gn_partial = gn_partial; a.gn_done = gn_done;
+  a.ln_partial = ln_partial; a.ln_parts_cap = ln_cap; a.ln_parts = ln_parts; a.ln_done = ln_done;
   a.A = d->A; a.W = d->W; a.C = d->C; a.bias = d->bias; a.res = d->res;
   a.M = d->M; a.N = d->N; a.K = d->K; a.lda = d->lda; a.ldc = d->ldc; a.ldr = d->ldr;
   a.mode = d->mode; a.H = d->H; a.Wd = d->Wd; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo;
@@ -167,6 +170,23 @@ int star_temporal_qkv_attn(star_ctx* h, const star_tq_desc* d) {
   a.A = d->A; a.W = d->W; a.O = d->O; a.bias = d->bias; a.colsum = d->colsum; a.rowab = d->rowab;
   a.lda = d->lda; a.ldo = d->ldo; a.HW = d->HW; a.F = d->F; a.C = d->C; a.heads = d->heads; a.scale = d->scale;
   return finish(h, op_temporal_qkv_attn(&h->c, a));
+}
+int star_gemm_rowstats(star_ctx* h, const star_gemm_desc* d, float* ln_partial, int32_t parts_cap, int32_t* parts, int32_t* wrote) {
+  bool done = false;
+  int np = 0;
+  if (wrote) *wrote = 0;
+  if (parts) *parts = 0;
+  if (!ln_partial || parts_cap <= 0) return finish(h, h->c.fail("gemm_rowstats: null partial buffer"));
+  const int rc = gemm_from_desc(h, d, nullptr, nullptr, ln_partial, parts_cap, &np, &done);
+  if (wrote) *wrote = done ? 1 : 0;
+  if (parts) *parts = done ? np : 0;
+  return rc;
+}
+int star_layer_norm_rowab_from_partials(star_ctx* h, const float* ln_partial, int32_t parts, float* rowab, int32_t rows, int32_t C, float eps,
+                                        int32_t mode, const float* gate_w, float* maps, int32_t H, int32_t W) {
+  if (h) rt::set_device(h->c.device);
+  if (!h) return 1;
+  return finish(h, op_layer_norm_from_partials(&h->c, ln_partial, parts, rows, C, eps, mode, gate_w, maps, H, W, rowab));
 }
 int star_group_norm_from_partials(star_ctx* h, const void* x, int32_t ldx, void* y, int32_t ldy, const float* gamma, const float* beta,
                                   int32_t rows, int32_t C, int32_t rows_per_stat, float eps, int32_t silu, const float* gn_partial) {

@@ -111,6 +111,7 @@ struct ProfRec { int kind; double flops; double bytes; void* e0; void* e1; int d
 struct Ctx {
   int device = 0;
   int num_cus = 256;          // compute units of the device (the GEMM launcher balances its last round of tiles against it)
+  long long ln_fused = 0;     // LayerNorm row-coefficient / map passes served from their producer's row statistics (diagnostic)
   long long gn_fused = 0;     // GroupNorms finalized from their producer's partial statistics instead of a statistics pass (diagnostic)
   long long gemm_splits = 0;  // launches the GEMM launcher split into full rounds of big tiles + a remainder of small ones (diagnostic)
   int dtype = DT_F16;

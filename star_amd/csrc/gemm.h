@@ -51,6 +51,11 @@ struct GemmParams {
   // (sum, sum of squares) of the STORED 16-bit outputs over the 32 rows of a slot, per PAIR of adjacent channels (a GroupNorm group
   // is an even number of channels, so a pair never straddles two groups).  Every (slot, pair) is written exactly once, in a fixed order.
   float* gn_partial;
+  // EPIF bit 5 (LayerNorm row statistics in the producer's epilogue, norm.h: ln_from_partials_kernel): ln_partial[M][ln_parts] x
+  // (sum, sum of squares, max, 0) fp32 of the STORED 16-bit outputs of row m over the columns of part = tile_n * WN + wave column
+  // (ln_parts = tiles_n * WN; every (row, part) is written exactly once)
+  float* ln_partial;
+  int ln_parts;
 };
 
 // exact (erf) GELU, F.gelu default (unet_v2v.py:504): gelu(x) = max(x, 0) - |x| q(|x|), q(t) = 0.5 erfc(t / sqrt 2).
@@ -104,7 +109,7 @@ STAR_DEV float gelu_tanh(float x) {
   return x * fast_rcp(1.0f + fast_exp2(-2.8853900817779268f * u));
 }
 
-template <class T, int BM, int BN, int WM, int WN, int AMODE, int MINW, bool F32OUT, bool STAGGER, int ABL = 0, int PIPE = 0, int EPIF = 0, int SCHED = 0>  // SCHED: hand-placed 2-stage loop for one wave per SIMD (4 waves x 128 x 128); ABL: ablation probes (bench only); PIPE: ring slots of the pipelined loop (0 = 2-stage loop); EPIF: 16-bit epilogue flavour (bit 0 residual add, bit 1 GEGLU, bit 2 tanh-GELU, bit 3 row-affine = folded LayerNorm, bit 4 GroupNorm partial statistics of the output)
+template <class T, int BM, int BN, int WM, int WN, int AMODE, int MINW, bool F32OUT, bool STAGGER, int ABL = 0, int PIPE = 0, int EPIF = 0, int SCHED = 0>  // SCHED: hand-placed 2-stage loop for one wave per SIMD (4 waves x 128 x 128); ABL: ablation probes (bench only); PIPE: ring slots of the pipelined loop (0 = 2-stage loop); EPIF: 16-bit epilogue flavour (bit 0 residual add, bit 1 GEGLU, bit 2 tanh-GELU, bit 3 row-affine = folded LayerNorm, bit 4 GroupNorm partial statistics of the output, bit 5 per-row (LayerNorm) partial statistics of the output)
 STAR_GLOBAL void STAR_LAUNCH_BOUNDS(WM * WN * 64, MINW)
 gemm_kernel(const GemmParams p) {
   constexpr int NT = WM * WN * 64;
@@ -661,6 +666,10 @@ gemm_kernel(const GemmParams p) {
     static_assert(!STATS || !(GEGLUF || GELUTF || ROWAFF), "GroupNorm statistics: plain and residual epilogues only");
     constexpr int RPP = 64 / cpr;
     constexpr int NPASS = STATS ? (32 + RPP - 1) / RPP : RUN;
+    // ROWST: per-row (sum, sum of squares, max) of the stored outputs over this wave's columns, for the LayerNorm that reads the tensor next
+    constexpr bool ROWST = (EPIF & 32) != 0;
+    static_assert(!ROWST || !(GEGLUF || GELUTF || ROWAFF || STATS), "row statistics: plain and residual epilogues only");
+    static_assert(!ROWST || (cpr % 2 == 0), "row statistics: two lanes share a row");
     // chunk u of this lane in a 32-row block: (row, chunk column); false = the lane has no chunk in this pass (STATS mapping only)
     auto chunk_of = [&](int u, int& row, int& cc) STAR_ALWAYS_INLINE -> bool {
       if constexpr (STATS) {
@@ -712,6 +721,10 @@ gemm_kernel(const GemmParams p) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) ov[e] = from_f32<T>(to_f32<T>(ov[e]) + to_f32<T>(rv[i][u][e]));
         }
+        if constexpr (ROWST && RESF) {   // the block in LDS becomes the STORED values (the row phase below reads it back row by row)
+          *reinterpret_cast<vec<T, 4>*>(my + row * pitch + cc * 16) = vec<T, 4>{ov[0], ov[1], ov[2], ov[3]};
+          *reinterpret_cast<vec<T, 4>*>(my + row * pitch + cc * 16 + 8) = vec<T, 4>{ov[4], ov[5], ov[6], ov[7]};
+        }
         if (act && m < p.M && n < N_out && (ABL != 5 || p.M < 0)) {
           // (non-temporal stores here are neutral, +-0.5 % on every level-0 shape: profiles/r05_cbench_gemm_nt.txt -- unlike the
           // A-stationary kernel, whose W panel lives in the L2 for the whole launch)
@@ -725,6 +738,38 @@ gemm_kernel(const GemmParams p) {
               pq[e] = dot2_acc<T>(pr, pr, pq[e]);
             }
           }
+        }
+      }
+      if constexpr (ROWST) {
+        // lane (r, hf) sums half of row r's chunks (fixed order), the two halves meet through a lane swap; one 16-byte record per row
+        wave_lds_fence();
+        const int r = lane & 31, hf = lane >> 5;
+        float rs = 0.f, rq = 0.f, rm = -3.0e38f;
+#pragma unroll
+        for (int c = 0; c < cpr / 2; ++c) {
+          const int cc = hf * (cpr / 2) + c;
+          if (out_n0 + cc * 8 < N_out) {   // wave-uniform per (hf, c) up to hf: both branches are cheap
+            const vec<T, 4> lo = *reinterpret_cast<const vec<T, 4>*>(my + r * pitch + cc * 16);
+            const vec<T, 4> hi = *reinterpret_cast<const vec<T, 4>*>(my + r * pitch + cc * 16 + 8);
+            vec<T, 8> v8;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v8[e] = lo[e]; v8[4 + e] = hi[e]; }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              vec<T, 2> pr;
+              pr[0] = v8[2 * e]; pr[1] = v8[2 * e + 1];
+              rs = dot2_one<T>(pr, rs);
+              rq = dot2_acc<T>(pr, pr, rq);
+            }
+            rm = fmaxf(rm, max8<T>(v8));
+          }
+        }
+        const float os = shfl_xor(rs, 32), oq = shfl_xor(rq, 32), om = shfl_xor(rm, 32);
+        const int mrow = m0 + wm * WTM + i * 32 + r;
+        if (hf == 0 && mrow < p.M) {
+          f32x4 rec;
+          rec[0] = rs + os; rec[1] = rq + oq; rec[2] = fmaxf(rm, om); rec[3] = 0.f;
+          *reinterpret_cast<f32x4*>(p.ln_partial + ((size_t)mrow * p.ln_parts + (size_t)(tile_n * WN + wn)) * 4) = rec;
         }
       }
       if constexpr (STATS) {

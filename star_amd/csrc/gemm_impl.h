@@ -19,6 +19,7 @@ static int launch_gemm_f(Ctx* ctx, const GemmArgs& a) {
   p.HW = a.HW; p.F = a.F; p.up_crop = a.up_crop; p.epi = a.epi;
   p.rowab = a.rowab; p.colsum = a.colsum;
   p.gn_partial = a.gn_partial;
+  p.ln_partial = a.ln_partial;
   p.m_off = a.m_off;
   p.tiles_m = ((a.m_end > 0 ? a.m_end : a.M) - a.m_off + BM - 1) / BM;
   p.tiles_n = (a.N + BN - 1) / BN;
@@ -39,6 +40,16 @@ static int launch_gemm_f(Ctx* ctx, const GemmArgs& a) {
   if (rowaff && (res || gelut || a.mode != A_PLAIN || !a.rowab || !a.colsum || !(a.epi & EPI_BIAS)))
     return ctx->fail("gemm: the folded-LayerNorm epilogue is for plain-A layers without a residual and needs rowab, colsum and bias");
 #define STAR_GEMM_GO(MODE, EF) STAR_LAUNCH((gemm_kernel<T, BM, BN, WM, WN, MODE, MINW, F32OUT, STAGGER, ABLV, PIPE, EF, SCHED>), grid, block, smem, ctx->stream, p)
+  if (a.ln_partial) {   // per-row statistics of the output (plain-A layers; checked by launch_gemm)
+    if constexpr (GNS && !F32OUT && SCHED == 0) {
+      p.ln_parts = p.tiles_n * WN;
+      if (a.mode != A_PLAIN || p.ln_parts > a.ln_parts_cap) return ctx->fail("gemm: row statistics: plain-A layers, parts within the caller's buffer");
+      if (res) STAR_GEMM_GO(A_PLAIN, 33); else STAR_GEMM_GO(A_PLAIN, 32);
+      if (a.ln_parts) *a.ln_parts = p.ln_parts;
+      if (a.ln_done) *a.ln_done = true;
+      return 0;
+    } else return ctx->fail("gemm: this tile has no row-statistics flavour");
+  }
   if (a.gn_partial) {   // the caller (launch_gemm) has checked mode and epilogue; the flavour exists for GNS tiles only
     if constexpr (GNS && !F32OUT) {
       switch (a.mode) {
@@ -121,7 +132,7 @@ static int launch_gemm(Ctx* ctx, const GemmArgs& a) {
     // to the 256 x 320 tile (N = 640 would waste a sixth of three 256-column tiles)
     // ... and whose tiles fill the resident workgroups' rounds to >= 88 % (the persistent walk is static: 1080 tiles on 256 CUs are 5
     // rounds for some workgroups; there the 256 x 320 tile + tail split measured ahead, profiles/r04_gemm_ab_v3_auto.txt)
-    bool persist_ok = gemm_persist_covers(a) && a.K >= 512 && a.N % 256 == 0 && a.N >= 1024 && !no_persist_env() && !a.gn_partial;
+    bool persist_ok = gemm_persist_covers(a) && a.K >= 512 && a.N % 256 == 0 && a.N >= 1024 && !no_persist_env() && !a.gn_partial && !a.ln_partial;
     if (persist_ok) {
       const int cus = a.assume_cus > 0 ? a.assume_cus : (ctx->num_cus > 0 ? ctx->num_cus : 256);
       const int64_t nt = (int64_t)((a.M + 255) / 256) * (a.N / 256), rounds = (nt + cus - 1) / cus;
@@ -137,6 +148,18 @@ static int launch_gemm(Ctx* ctx, const GemmArgs& a) {
     else if (a.N <= 128) tile = 4;
     else tile = 1;
   }
+  // LayerNorm row statistics in the epilogue: tiles 2 and 3, plain-A layers with the bias (+ residual) 16-bit epilogue, never together
+  // with the GroupNorm partials; elsewhere the request is dropped (ln_done stays false)
+  if (a.ln_partial) {
+    const int bn = tile == 2 ? 320 : 128;
+    const bool ok_ = (tile == 2 || tile == 3) && a.mode == A_PLAIN && !a.gn_partial &&
+                     !(a.epi & (EPI_OUT_F32 | EPI_ROWAFF | EPI_GELU_TANH | EPI_GEGLU)) && !(a.N & 7) && ((a.N + bn - 1) / bn) * 2 <= a.ln_parts_cap;
+    if (!ok_) {
+      GemmArgs b = a;
+      b.ln_partial = nullptr;
+      return launch_gemm<T>(ctx, b);
+    }
+  }
   // GroupNorm statistics in the epilogue: the flavour exists for tiles 2, 3 and 17 on plain / 3x3 / temporal-conv layers with the
   // bias (+ residual) 16-bit epilogue; elsewhere the request is dropped (gn_done stays false: the consumer runs its own pass)
   if (a.gn_partial && (!(tile == 2 || tile == 3 || tile == 17) || !(a.mode == A_PLAIN || a.mode == A_CONV3X3 || a.mode == A_TCONV3) ||
@@ -150,7 +173,7 @@ static int launch_gemm(Ctx* ctx, const GemmArgs& a) {
   // their time with three quarters of the chip idle.  When the last round is poorly filled, the launch covers only the tile rows of
   // the FULL rounds and the remaining rows go to a second launch of 128 x 128 tiles (tile 3: two workgroups per CU, every mode and
   // epilogue flavour, same k order per output -- bit-identical).  Decided by a cost model in units of one big tile's time.
-  if (!a.force_tile && a.m_off == 0 && a.m_end == 0 && (tile == 1 || tile == 2 || tile == 17)) {   // (the persistent tile 18 is only chosen where its rounds are full)
+  if (!a.force_tile && a.m_off == 0 && a.m_end == 0 && !a.ln_partial && (tile == 1 || tile == 2 || tile == 17)) {   // (row statistics: the remainder tile would cut the rows into a different number of parts)   // (the persistent tile 18 is only chosen where its rounds are full)
     const int cus = a.assume_cus > 0 ? a.assume_cus : (ctx->num_cus > 0 ? ctx->num_cus : 256);
     const int bm = 256, bn = tile == 2 ? 320 : 256;
     const long long tm = (a.M + bm - 1) / bm, tn = (a.N + bn - 1) / bn, nt = tm * tn;

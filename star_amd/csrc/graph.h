@@ -240,8 +240,10 @@ struct Act {          // an activation tensor: rows = F*H*W tokens; the buffer r
   // GroupNorm partial statistics of THIS tensor, written by the kernel that produced it (GemmArgs::gn_partial): a GroupNorm that
   // reads the tensor finalizes from them instead of running its own statistics pass; null = none
   std::shared_ptr<Buf> gnp;
+  // ... and its per-row (LayerNorm) statistics (GemmArgs::ln_partial, ln_parts parts per row)
+  std::shared_ptr<Buf> lnp; int ln_parts = 0;
   void* p() const { return buf ? buf->p : nullptr; }
-  void drop() { buf.reset(); gnp.reset(); }
+  void drop() { buf.reset(); gnp.reset(); lnp.reset(); ln_parts = 0; }
 };
 
 
@@ -265,26 +267,39 @@ struct Runner {
   // GroupNorm statistics in the producers' epilogues (STAR_NO_GNEPI=1: every GroupNorm runs its own statistics pass; A/B switch, read once)
   static bool gn_epi_enabled() { static const bool v = std::getenv("STAR_NO_GNEPI") == nullptr; return v; }
   // op_gemm producing y; `stats`: also ask for y's GroupNorm partials (kept on y only if the launched tile wrote them)
-  void gemm_to(GemmArgs& g, Act* y, bool stats) {
-    bool done = false;
-    std::shared_ptr<Buf> part;
+  // rowstats: ask for y's per-row statistics instead (the next reader is a LayerNorm; levels of width <= 640: wider layers are
+  // tail-split, and the remainder tile would cut their rows into a different number of parts)
+  void gemm_to(GemmArgs& g, Act* y, bool stats, bool rowstats = false) {
+    bool done = false, ldone = false;
+    int lparts = 0;
+    std::shared_ptr<Buf> part, lpart;
     if (stats && y && gn_epi_enabled() && !(g.N & 63)) {
       part = std::make_shared<Buf>(ctx, (size_t)((g.M + 31) / 32) * g.N * sizeof(float));
       if (part->p) { g.gn_partial = part->as<float>(); g.gn_done = &done; }
+    } else if (rowstats && y && ln_epi_enabled() && g.mode == A_PLAIN && g.N <= 640 && !(g.N & 7)) {
+      const int cap = 2 * ((g.N + 127) / 128);
+      lpart = std::make_shared<Buf>(ctx, (size_t)g.M * cap * 4 * sizeof(float));
+      if (lpart->p) { g.ln_partial = lpart->as<float>(); g.ln_parts_cap = cap; g.ln_parts = &lparts; g.ln_done = &ldone; }
     }
     ok(op_gemm(ctx, g));
-    if (y) y->gnp = done ? part : nullptr;
+    if (y) {
+      y->gnp = done ? part : nullptr;
+      y->lnp = ldone ? lpart : nullptr;
+      y->ln_parts = ldone ? lparts : 0;
+    }
   }
+  // LayerNorm row statistics in the producers' epilogues (STAR_NO_LNEPI=1: every LayerNorm reads its rows; A/B switch, read once)
+  static bool ln_epi_enabled() { static const bool v = std::getenv("STAR_NO_LNEPI") == nullptr; return v; }
 
   // y = x W^T (+b) (+res)
   void gemm(const void* A, int lda, int M, const LinW& w, void* C, int ldc, const void* res = nullptr, int ldr = 0, int extra_epi = 0,
-            const float* bias_override = nullptr, Act* stats_of = nullptr) {   // stats_of: the Act that C is (dense, ldc == N): ask for its GroupNorm partials
+            const float* bias_override = nullptr, Act* stats_of = nullptr, Act* rowstats_of = nullptr) {   // stats_of / rowstats_of: the Act that C is (dense, ldc == N): ask for its GroupNorm partials / LayerNorm row statistics
     GemmArgs g;
     g.A = A; g.W = w.w.p; g.C = C; g.M = M; g.N = w.N; g.K = w.K; g.lda = lda; g.ldc = ldc;
     g.bias = bias_override ? bias_override : (const float*)w.b.p;
     g.res = res; g.ldr = ldr;
     g.epi = (g.bias ? EPI_BIAS : 0) | (res ? EPI_RES : 0) | extra_epi;
-    gemm_to(g, stats_of, stats_of != nullptr);
+    gemm_to(g, stats_of ? stats_of : rowstats_of, stats_of != nullptr, rowstats_of != nullptr);
   }
   void conv3x3(const Act& x, const LinW& w, Act& y, int mode, int stride, int pad_t, int pad_l, const void* res, const float* bias_override = nullptr,
                int extra_epi = 0, void* out_override = nullptr, int ldc_override = 0, int up_crop = 1, bool stats = false) {
@@ -311,6 +326,13 @@ struct Runner {
   // the row statistics of a LayerNorm that is folded into the next GEMM: rowab[m] = (a_m, b_m); x is read once, nothing is written back
   void ln_rows(const void* x, float* rowab, int rws, int C, int mode = LN_PLAIN, const float* gw = nullptr, float* maps = nullptr, int H = 0, int W = 0) {
     ok(op_layer_norm(ctx, x, C, nullptr, C, nullptr, nullptr, rws, C, 1e-5f, mode, gw, maps, H, W, rowab));
+  }
+  // the same for an activation whose producer left its row statistics (gemm(..., rowstats_of)): 16 x parts bytes per row instead of the row
+  void ln_rows(const Act& x, float* rowab, int rws, int C, int mode = LN_PLAIN, const float* gw = nullptr, float* maps = nullptr, int H = 0, int W = 0) {
+    if (x.lnp && x.lnp->p && x.ln_parts > 0)
+      ok(op_layer_norm_from_partials(ctx, x.lnp->as<float>(), x.ln_parts, rws, C, 1e-5f, mode, gw, maps, H, W, rowab));
+    else
+      ln_rows(x.p(), rowab, rws, C, mode, gw, maps, H, W);
   }
   // y = LN(x) W^T + b through the folded form (w built by Builder::*_ln)
   void gemm_ln(const void* A, int lda, int M, const LinW& w, const float* rowab, void* C, int ldc, int extra_epi = 0) {

@@ -150,6 +150,20 @@ int op_layer_norm(Ctx* ctx, const void* x, int ldx, void* y, int ldy, const floa
   return ln_t<bf16>(ctx, p);
 }
 
+// the row coefficients / LIEM maps of a LayerNorm from the row statistics its input's producer wrote (GemmArgs::ln_partial)
+int op_layer_norm_from_partials(Ctx* ctx, const float* partial, int parts, int rows, int C, float eps, int mode, const float* gate_w,
+                                float* maps, int H, int W, float* rowab) {
+  if (rows <= 0) return 0;
+  if (!partial || parts <= 0) return ctx->fail("layer_norm_from_partials: no partials");
+  if (mode == LN_STATS_ONLY ? !maps : !rowab) return ctx->fail("layer_norm_from_partials: null output");
+  if ((mode == LN_GATE_LINEAR && !gate_w) || (mode == LN_GATE_MAP && (!gate_w || !maps || H * W <= 0))) return ctx->fail("layer_norm_from_partials: gate operands missing");
+  ProfScope ps(ctx, PK_LN, 0.0, (double)rows * parts * 16.0);
+  ++ctx->ln_fused;
+  LnPartParams p{partial, parts, gate_w, maps, rowab, C, rows, H, W, eps, mode};
+  STAR_LAUNCH(ln_from_partials_kernel, dim3((unsigned)((rows + 31) / 32)), dim3(256), (size_t)0, ctx->stream, p);
+  return 0;
+}
+
 int op_concat_add(Ctx* ctx, const void* a, const void* b, const void* c, void* out, int rows, int C1, int C2, float* gn_partial) {
   ProfScope ps(ctx, PK_MISC, 0.0, 2.0 * rows * (double)(C1 + C2 + (c ? C2 : 0)) * 2.0);
   if ((C1 | C2) & 7) return ctx->fail("concat_add: channel counts must be multiples of 8");

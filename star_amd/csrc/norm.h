@@ -383,6 +383,64 @@ STAR_GLOBAL void ln_kernel(const LnParams p) {
   }
 }
 
+// ------------------------------------------------------------------ LayerNorm row coefficients from the PRODUCER's row statistics
+// The GEMM that wrote x also wrote, per row and column part, (sum, sum of squares, max) of the stored values (gemm.h EPIF bit 5): the
+// LayerNorms that are folded into the next projection (rowab: LN(gate x) = (a x + b) gamma + beta) and the LIEM maps need nothing
+// else of x -- 16 x parts bytes per row instead of the row itself (2 parts at C = 320: 32 of 640 bytes).  Same modes and outputs as
+// ln_kernel: LN_STATS_ONLY -> maps[token] = (max_c, mean_c); LN_PLAIN / LN_GATE_LINEAR / LN_GATE_MAP -> rowab[token] = (a, b).
+// The variance is E[x^2] - mean^2 from fp32 sums of exact 16-bit squares, finished in double.  Eight lanes per row (the 7x7 taps of
+// the map gate are shared among them as in ln_kernel).
+struct LnPartParams {
+  const float* partial; int parts;
+  const float* gate_w; float* maps; float* rowab;
+  int C, rows, H, W; float eps; int mode;
+};
+STAR_GLOBAL void ln_from_partials_kernel(const LnPartParams p) {
+  constexpr int LPR = 8;
+  const int lane = threadIdx.x & 63;
+  const int sub = lane & (LPR - 1), rowi = lane / LPR, rpw = 64 / LPR;
+  const int row = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * rpw + rowi;
+  const bool active = row < p.rows;
+  const int rr = active ? row : p.rows - 1;
+  auto group_sum = [&](float v) { for (int m = LPR >> 1; m >= 1; m >>= 1) v += shfl_xor(v, m); return v; };
+  auto group_max = [&](float v) { for (int m = LPR >> 1; m >= 1; m >>= 1) v = fmaxf(v, shfl_xor(v, m)); return v; };
+  float s = 0.f, q = 0.f, mx = -3.0e38f;
+  for (int pt = sub; pt < p.parts; pt += LPR) {
+    const f32x4 rec = *reinterpret_cast<const f32x4*>(p.partial + ((size_t)rr * p.parts + pt) * 4);
+    s += rec[0]; q += rec[1]; mx = fmaxf(mx, rec[2]);
+  }
+  s = group_sum(s); q = group_sum(q); mx = group_max(mx);
+  const float inv_c = 1.0f / (float)p.C;
+  float mean = s * inv_c;
+  if (p.mode == LN_STATS_ONLY) {
+    if (active && sub == 0) { p.maps[2 * (size_t)row] = mx; p.maps[2 * (size_t)row + 1] = mean; }
+    return;
+  }
+  double var = (double)q * (double)inv_c - (double)mean * (double)mean;
+  if (var < 0.0) var = 0.0;
+  float gate = 1.0f;
+  if (p.mode == LN_GATE_LINEAR) {
+    gate = sigmoid_f(p.gate_w[0] * mx + p.gate_w[1] * mean);
+  } else if (p.mode == LN_GATE_MAP) {
+    const int hw = p.H * p.W;
+    const int f = rr / hw, rem = rr - f * hw;
+    const int y = rem / p.W, x = rem - y * p.W;
+    float acc = 0.f;
+    for (int tap = sub; tap < 98; tap += LPR) {
+      const int ch = tap / 49, k = tap - ch * 49;
+      const int dy = k / 7 - 3, dx = k - (k / 7) * 7 - 3;
+      const int yy = y + dy, xx = x + dx;
+      if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W)
+        acc += p.gate_w[tap] * p.maps[2 * ((size_t)f * hw + (size_t)yy * p.W + xx) + ch];
+    }
+    gate = sigmoid_f(group_sum(acc));
+  }
+  // the gated row g x has mean g mean and variance g^2 var
+  const float gm = gate * mean;
+  const float rstd = (float)(1.0 / sqrt((double)gate * (double)gate * var + (double)p.eps));
+  if (active && sub == 0) { p.rowab[2 * (size_t)row] = gate * rstd; p.rowab[2 * (size_t)row + 1] = -rstd * gm; }
+}
+
 // ------------------------------------------------------------------ elementwise plumbing
 // out[row] = concat(a[row][0:C1], b[row][0:C2] (+ c[row][0:C2]))   (unet_v2v.py:1792 torch.cat([x, xs.pop() + control.pop()]))
 struct ConcatParams { const void* a; const void* b; const void* c; void* out; int C1, C2, rows; };

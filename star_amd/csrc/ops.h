@@ -39,6 +39,14 @@ struct GemmArgs {
   // bias (+ residual) epilogue) -- *gn_done says whether it was; otherwise the consumer runs its own statistics pass
   float* gn_partial = nullptr;
   bool* gn_done = nullptr;
+  // LayerNorm row statistics in this layer's epilogue (gemm.h EPIF bit 5): ln_partial[M][parts][4] fp32 = (sum, sum of squares, max, 0) of
+  // the stored outputs per row and column part; the launcher writes the number of parts (<= ln_parts_cap, which sized the buffer) to
+  // *ln_parts and sets *ln_done when the launched tile has the flavour (256 x 320 and 128 x 128 tiles, plain-A layers, bias (+ residual)
+  // 16-bit epilogue); otherwise the consumer runs its own pass over the rows
+  float* ln_partial = nullptr;
+  int ln_parts_cap = 0;
+  int* ln_parts = nullptr;
+  bool* ln_done = nullptr;
 };
 int op_gemm(Ctx* ctx, const GemmArgs& a);
 
@@ -95,6 +103,10 @@ int op_gn_fold_weights(Ctx* ctx, const void* W, const float* bias, const float* 
 int op_layer_norm(Ctx* ctx, const void* x, int ldx, void* y, int ldy, const float* gamma, const float* beta,
                   int rows, int C, float eps, int mode, const float* gate_w, float* maps, int H, int W, float* rowab = nullptr);
 // gn_partial (optional): also write the output's GroupNorm partial statistics [ceil(rows / 32)][(C1 + C2) / 2][2] (GemmArgs::gn_partial layout)
+// LayerNorm row coefficients (rowab) / LIEM maps from the row statistics the input's producer wrote (GemmArgs::ln_partial): same modes as
+// op_layer_norm with rowab / STATS_ONLY outputs, 16 x parts bytes read per row
+int op_layer_norm_from_partials(Ctx* ctx, const float* partial, int parts, int rows, int C, float eps, int mode, const float* gate_w,
+                                float* maps, int H, int W, float* rowab);
 int op_concat_add(Ctx* ctx, const void* a, const void* b, const void* c, void* out, int rows, int C1, int C2, float* gn_partial = nullptr);
 int op_add(Ctx* ctx, const void* a, const void* b, void* out, long long n);
 int op_stem_im2col(Ctx* ctx, const float* latent, void* out, int Cl, int F, int H, int W, bool frame_major = false);

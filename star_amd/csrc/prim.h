@@ -623,6 +623,24 @@ STAR_DEV vec<T, 2> pk_add(vec<T, 2> a, vec<T, 2> b) {
   return a + b;
 #endif
 }
+// max of the 8 values of a 16-byte chunk (f16: a tree of v_pk_max_f16)
+template <class T>
+STAR_DEV float max8(vec<T, 8> v) {
+#ifndef STAR_HOSTEMU
+  if constexpr (__is_same(T, f16)) {
+    vec<f16, 2> a, b, c, d;
+    a[0] = v[0]; a[1] = v[1]; b[0] = v[2]; b[1] = v[3]; c[0] = v[4]; c[1] = v[5]; d[0] = v[6]; d[1] = v[7];
+    a = __builtin_elementwise_max(a, b);
+    c = __builtin_elementwise_max(c, d);
+    a = __builtin_elementwise_max(a, c);
+    return fmaxf((float)a[0], (float)a[1]);
+  }
+#endif
+  float m = to_f32<T>(v[0]);
+#pragma unroll
+  for (int e = 1; e < 8; ++e) m = fmaxf(m, to_f32<T>(v[e]));
+  return m;
+}
 // compile-time scheduling hint (LLVM sched_group_barrier): emit `n` instructions of class `mask` next
 #ifdef STAR_HOSTEMU
 #define STAR_SCHED_GROUP(mask, n, id)

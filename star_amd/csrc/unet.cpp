@@ -132,7 +132,7 @@ struct Fwd : Runner {
   // shared tail of both transformer kinds: LN3 -> GEGLU FF -> +res ; then proj_out (+ x_in)
   void ff_and_out(const TBlockW& tb, Act& h2, int R, int inner, const LinW& proj_out, const Act& x_in, Act& out) {
     Buf ab(ctx, (size_t)R * 2 * 4);
-    ln_rows(h2.p(), ab.as<float>(), R, inner);                         // norm3, folded into the GEGLU projection
+    ln_rows(h2, ab.as<float>(), R, inner);                             // norm3, folded into the GEGLU projection (row statistics from h2's producer where it left them)
     Buf g(ctx, (size_t)R * inner * 4 * es);
     if (!g.p || !ab.p) { rc = ctx->fail("out of device memory (ff)"); return; }
     gemm_ln(h2.p(), inner, R, tb.ff1, ab.as<float>(), g.p, inner * 4, EPI_GEGLU);
@@ -154,11 +154,11 @@ struct Fwd : Runner {
     Act n = make(C, x.H, x.W);
     gn(x, s.norm, n, false, 1e-6f, false);
     Act h = make(C, x.H, x.W);
-    gemm(n.p(), C, R, s.proj_in, h.p(), C);
-    // LIEM spatial gate + LN1 (folded into the QKV projection: rows of h are read for their statistics only)
+    gemm(n.p(), C, R, s.proj_in, h.p(), C, nullptr, 0, 0, nullptr, nullptr, &h);   // + h's row statistics
+    // LIEM spatial gate + LN1 (folded into the QKV projection: rows of h are read for their statistics only -- or not at all)
     Buf maps(ctx, (size_t)R * 2 * 4), ab(ctx, (size_t)R * 2 * 4);
-    ln_rows(h.p(), nullptr, R, C, LN_STATS_ONLY, nullptr, maps.as<float>());
-    ln_rows(h.p(), ab.as<float>(), R, C, LN_GATE_MAP, (const float*)tb.local1.p, maps.as<float>(), x.H, x.W);
+    ln_rows(h, nullptr, R, C, LN_STATS_ONLY, nullptr, maps.as<float>());
+    ln_rows(h, ab.as<float>(), R, C, LN_GATE_MAP, (const float*)tb.local1.p, maps.as<float>(), x.H, x.W);
     maps.reset();
     // self attention over the H*W tokens of each frame
     Buf qkv(ctx, (size_t)R * 3 * C * es);
@@ -175,7 +175,7 @@ struct Fwd : Runner {
     }
     qkv.reset();
     mid.h1 = make(C, x.H, x.W);
-    gemm(n.p(), C, R, tb.out1, mid.h1.p(), C, h.p(), C);
+    gemm(n.p(), C, R, tb.out1, mid.h1.p(), C, h.p(), C, 0, nullptr, nullptr, &mid.h1);   // + h1's row statistics (norm2)
     return mid;
   }
   Act st_cross(const STW& s, const STMid& mid, const void* context_T) {
@@ -184,7 +184,7 @@ struct Fwd : Runner {
     const TBlockW& tb = s.tb;
     Act n = make(C, x.H, x.W);
     Buf ab(ctx, (size_t)R * 2 * 4);
-    ln_rows(mid.h1.p(), ab.as<float>(), R, C);                          // norm2, folded into to_q
+    ln_rows(mid.h1, ab.as<float>(), R, C);                              // norm2, folded into to_q
     Act q2 = make(C, x.H, x.W);
     if (!ab.p) { rc = ctx->fail("out of device memory"); return n; }
     gemm_ln(mid.h1.p(), C, R, tb.q2, ab.as<float>(), q2.p(), C);
@@ -201,7 +201,7 @@ struct Fwd : Runner {
     }
     q2.drop(); kv.reset();
     Act h2 = make(C, x.H, x.W);
-    gemm(n.p(), C, R, tb.out2, h2.p(), C, mid.h1.p(), C);
+    gemm(n.p(), C, R, tb.out2, h2.p(), C, mid.h1.p(), C, 0, nullptr, nullptr, &h2);   // + h2's row statistics (norm3)
     n.drop();
     Act out = make(C, x.H, x.W);
     ff_and_out(tb, h2, R, C, s.proj_out, x, out);
@@ -233,11 +233,11 @@ struct Fwd : Runner {
       ok(op_group_norm_stats(ctx, x.p(), x.C, (const float*)s.norm.g.p, (const float*)s.norm.b.p, R, C, R, 1e-6f, ab.as<float>(), mu.as<float>()));
       ok(op_gn_fold_weights(ctx, s.proj_in.w.p, (const float*)s.proj_in.b.p, ab.as<float>(), w2.p, b2.as<float>(), I, C, mu.as<float>()));
       LinW folded; folded.N = I; folded.K = C; folded.w.p = w2.p;
-      gemm(x.p(), C, R, folded, h.p(), I, nullptr, 0, 0, b2.as<float>());
+      gemm(x.p(), C, R, folded, h.p(), I, nullptr, 0, 0, b2.as<float>(), nullptr, &h);   // + h's row statistics (temporal gate + norm1)
     } else {
       Act xn = make(C, x.H, x.W);
       gn(x, s.norm, xn, true, 1e-6f, false);
-      gemm(xn.p(), C, R, s.proj_in, h.p(), I);
+      gemm(xn.p(), C, R, s.proj_in, h.p(), I, nullptr, 0, 0, nullptr, nullptr, &h);
     }
     Act l = make(I, x.H, x.W);
     Buf qkv(ctx, (size_t)R * 3 * I * es), ab(ctx, (size_t)R * 2 * 4);
@@ -245,7 +245,7 @@ struct Fwd : Runner {
     Act cur = std::move(h);
     for (int pass = 0; pass < 2; ++pass) {
       // temporal LIEM gate + LayerNorm, folded into the QKV projection
-      ln_rows(cur.p(), ab.as<float>(), R, I, LN_GATE_LINEAR, (const float*)(pass == 0 ? tb.local1.p : tb.local2.p));
+      ln_rows(cur, ab.as<float>(), R, I, LN_GATE_LINEAR, (const float*)(pass == 0 ? tb.local1.p : tb.local2.p));
       const LinW& tq = pass == 0 ? tb.qkv1_tq : tb.qkv2_tq;
       if (use_tq && tq.w.p && temporal_qkv_attn_covers(I, s.heads, F)) {
         // projection + attention in one kernel (gemm_tq.h): q | k | v never reach HBM; bit-identical to the two kernels below
@@ -261,7 +261,7 @@ struct Fwd : Runner {
       ok(op_temporal_attn(ctx, a));
       }
       Act nx = make(I, x.H, x.W);
-      gemm(l.p(), I, R, pass == 0 ? tb.out1 : tb.out2, nx.p(), I, cur.p(), I);
+      gemm(l.p(), I, R, pass == 0 ? tb.out1 : tb.out2, nx.p(), I, cur.p(), I, 0, nullptr, nullptr, &nx);   // + nx's row statistics (next pass / norm3)
       cur = std::move(nx);
     }
     qkv.reset(); l.drop(); ab.reset();

@@ -114,8 +114,10 @@ class Library:
         self.pool_peak_bytes = _sig(c, "star_pool_peak_bytes", sz, vp)
         self.gemm_split_count = _sig(c, "star_gemm_split_count", i64, vp)
         self.gn_fused_count = _sig(c, "star_gn_fused_count", i64, vp)
+        self.ln_fused_count = _sig(c, "star_ln_fused_count", i64, vp)
         self.gemm = _sig(c, "star_gemm", i32, vp, ctypes.POINTER(GemmDesc))
         self.gemm_gn = _sig(c, "star_gemm_gn", i32, vp, ctypes.POINTER(GemmDesc), vp, ctypes.POINTER(ctypes.c_int32))
+        self.gemm_rowstats = _sig(c, "star_gemm_rowstats", i32, vp, ctypes.POINTER(GemmDesc), vp, i32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32))
         f32 = ctypes.c_float
         self.attn_fwd = _sig(c, "star_attn_fwd", i32, vp, ctypes.POINTER(AttnDesc))
         self.temporal_attn_fwd = _sig(c, "star_temporal_attn_fwd", i32, vp, ctypes.POINTER(TAttnDesc))
@@ -123,6 +125,7 @@ class Library:
         self.group_norm = _sig(c, "star_group_norm", i32, vp, vp, i32, vp, i32, vp, vp, i32, i32, i32, f32, i32)
         self.group_norm_from_partials = _sig(c, "star_group_norm_from_partials", i32, vp, vp, i32, vp, i32, vp, vp, i32, i32, i32, f32, i32, vp)
         self.layer_norm = _sig(c, "star_layer_norm", i32, vp, vp, i32, vp, i32, vp, vp, i32, i32, f32, i32, vp, vp, i32, i32)
+        self.layer_norm_rowab_from_partials = _sig(c, "star_layer_norm_rowab_from_partials", i32, vp, vp, i32, vp, i32, i32, ctypes.c_float, i32, vp, vp, i32, i32)
         self.layer_norm_rowab = _sig(c, "star_layer_norm_rowab", i32, vp, vp, i32, vp, i32, i32, f32, i32, vp, vp, i32, i32)
         self.concat_add = _sig(c, "star_concat_add", i32, vp, vp, vp, vp, vp, i32, i32, i32)
         self.add = _sig(c, "star_add", i32, vp, vp, vp, vp, i64)
@@ -244,11 +247,13 @@ class Context:
 
     # ------------------------------------------------------------------ kernels
     def gemm(self, A, W, bias=None, res=None, out=None, *, mode=A_PLAIN, M=None, conv=None, temporal=None,
-             geglu=False, out_f32=False, force_tile=0, up_crop=1, gelu_tanh=False, rowab=None, colsum=None, gn_partial=False):
+             geglu=False, out_f32=False, force_tile=0, up_crop=1, gelu_tanh=False, rowab=None, colsum=None, gn_partial=False, row_stats=False):
         """out[M, N] = epilogue(A' @ W^T).  A: [rows, lda] activations (channels-last tokens);
         W: [N, K]; conv=(NB,H,Wd,Cin,Ho,Wo,stride,pad_t,pad_l); temporal=(F,HW,Cin).
         gn_partial=True: star_gemm_gn -- returns (out, partial) with partial fp32 [ceil(M/32), N/2, 2] = the GroupNorm partial statistics of
-        out written by the epilogue, or (out, None) when the launcher's tile has no such flavour."""
+        out written by the epilogue, or (out, None) when the launcher's tile has no such flavour.
+        row_stats=True: star_gemm_rowstats -- returns (out, partial) with partial fp32 [M, parts, 4] = per-row (sum, sum of squares, max, 0) of
+        out per column part, or (out, None)."""
         self._chk_tensor(A, self.dtype); self._chk_tensor(W, self.dtype)
         self._chk_tensor(bias, torch.float32); self._chk_tensor(res, self.dtype)
         N, K = W.shape
@@ -283,6 +288,14 @@ class Context:
             d.rowab, d.colsum = rowab.data_ptr(), colsum.data_ptr()
             d.epi |= EPI_ROWAFF
         d.force_tile = force_tile
+        if row_stats:
+            cap = 2 * ((N + 127) // 128)
+            part = torch.zeros(M, cap, 4, dtype=torch.float32, device=self.torch_device)
+            wrote, parts = ctypes.c_int32(0), ctypes.c_int32(0)
+            self._check(self.lib.gemm_rowstats(self.h, ctypes.byref(d), _ptr(part), cap, ctypes.byref(parts), ctypes.byref(wrote)), "gemm_rowstats")
+            if not wrote.value:
+                return out, None
+            return out, part.reshape(-1)[: M * parts.value * 4].reshape(M, parts.value, 4)
         if gn_partial:
             part = torch.empty((M + 31) // 32, N // 2, 2, dtype=torch.float32, device=self.torch_device)
             wrote = ctypes.c_int32(0)
@@ -390,6 +403,20 @@ class Context:
         self._check(self.lib.layer_norm_rowab(self.h, _ptr(x), x.stride(0), _ptr(rowab), rows, C, float(eps), mode, _ptr(gate_w),
                                               _ptr(maps), H, W), "layer_norm_rowab")
         return rowab
+
+    def layer_norm_rowab_from_partials(self, partial, C, eps=1e-5, mode=LN_PLAIN, gate_w=None, maps=None, H=0, W=0):
+        """layer_norm_rowab (mode 3: the LIEM maps, returned instead) from the producer's row statistics (gemm(..., row_stats=True))"""
+        self._chk_tensor(partial, torch.float32)
+        rows, parts, _ = partial.shape
+        assert partial.is_contiguous()
+        if mode == LN_STATS_ONLY:
+            maps = torch.empty(rows, 2, dtype=torch.float32, device=self.torch_device)
+            rowab = None
+        else:
+            rowab = torch.empty(rows, 2, dtype=torch.float32, device=self.torch_device)
+        self._check(self.lib.layer_norm_rowab_from_partials(self.h, _ptr(partial), parts, _ptr(rowab), rows, C, float(eps), mode, _ptr(gate_w),
+                                                            _ptr(maps), H, W), "layer_norm_rowab_from_partials")
+        return maps if mode == LN_STATS_ONLY else rowab
 
     def concat_add(self, a, b, c=None):
         rows, C1 = a.shape

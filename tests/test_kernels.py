@@ -753,3 +753,50 @@ def test_group_norm_statistics_in_the_producer_epilogue(ctx, dtype, mode, tile, 
     # a tile without the flavour: the output is still computed, no partials
     out4, part4 = ctx.gemm(a, w, bias=b, res=res, force_tile=4 if mode == "plain" else 1, gn_partial=True, **kw)
     assert part4 is None and out4.shape == out.shape
+
+
+ROWSTAT_CASES = [   # tile, (frames, H, W), K, N, residual
+    (2, (2, 11, 9), 192, 320, True),     # out-projection + residual at level-0 width: one 320-column tile, two wave columns of 160 = 2 parts
+    (2, (2, 11, 9), 128, 640, False),    # proj_in at level-1 width: 4 parts
+    (3, (3, 10, 8), 64, 192, True),      # 128 x 128 tile, ragged last column tile (the second wave column of the last tile is empty)
+    (3, (2, 9, 7), 64, 128, False),
+]
+
+
+@pytest.mark.parametrize("tile,geom,K,N,with_res", ROWSTAT_CASES)
+def test_layer_norm_row_statistics_in_the_producer_epilogue(ctx, dtype, tile, geom, K, N, with_res):
+    """star_gemm_rowstats + star_layer_norm_rowab_from_partials (gemm.h EPIF bit 5, norm.h ln_from_partials_kernel; unet_v2v.py:448-450,
+    466-490): the layer's output is bit-identical to star_gemm's; the per-row records are (sum, sum of squares, max) of the STORED outputs
+    over each column part; the row coefficients / LIEM maps derived from them match star_layer_norm_rowab / star_layer_norm (mode 3) on the
+    stored tensor in all four modes -- also on rows whose mean is ten times their spread."""
+    Fr, H, Wd = geom
+    g = torch.Generator().manual_seed(K + N + tile)
+    M = Fr * H * Wd
+    a = dev(ctx, torch.randn(M, K, generator=g).to(dtype))
+    w = dev(ctx, (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dtype))
+    bias = torch.randn(N, generator=g)
+    bias[: N // 2] += 6.0                                   # a large common offset: |row mean| >> spread for E[x^2] - mean^2
+    b = dev(ctx, bias)
+    res = dev(ctx, (torch.randn(M, N, generator=g) * 0.5).to(dtype)) if with_res else None
+    plain = ctx.gemm(a, w, bias=b, res=res, force_tile=tile)
+    out, part = ctx.gemm(a, w, bias=b, res=res, force_tile=tile, row_stats=True)
+    assert part is not None and torch.equal(out, plain)
+    o = out.double().cpu()
+    p = part.double().cpu()
+    assert (p[..., 0].sum(1) - o.sum(1)).abs().max().item() <= 1e-5 * (o.abs().sum(1).max().item() + 1)
+    assert (p[..., 1].sum(1) - (o * o).sum(1)).abs().max().item() <= 2e-5 * ((o * o).sum(1).max().item() + 1)
+    assert torch.equal(p[..., 2].max(1).values, o.max(1).values)
+    # the consumers: maps, plain, linear gate, 7x7-map gate
+    maps = ctx.layer_norm_rowab_from_partials(part, N, mode=L.LN_STATS_ONLY)
+    maps0 = torch.empty(M, 2, dtype=torch.float32, device=ctx.torch_device)
+    ctx.layer_norm(out, dev(ctx, torch.ones(N)), dev(ctx, torch.zeros(N)), mode=L.LN_STATS_ONLY, maps=maps0)
+    assert (maps.cpu() - maps0.cpu()).abs().max().item() <= 1e-4
+    w2 = dev(ctx, torch.randn(2, generator=g))
+    w98 = dev(ctx, torch.randn(98, generator=g) * 0.2)
+    for mode, gw, mp in ((L.LN_PLAIN, None, None), (L.LN_GATE_LINEAR, w2, None), (L.LN_GATE_MAP, w98, maps0)):
+        ab = ctx.layer_norm_rowab_from_partials(part, N, mode=mode, gate_w=gw, maps=mp, H=H, W=Wd).cpu()
+        ab0 = ctx.layer_norm_rowab(out, mode=mode, gate_w=gw, maps=mp, H=H, W=Wd).cpu()
+        rel = ((ab - ab0).abs() / (ab0.abs() + 1e-3)).max().item()
+        assert rel <= 2e-3, (mode, rel)
+    out1, part1 = ctx.gemm(a, w, bias=b, res=res, force_tile=1, row_stats=True)   # a tile without the flavour
+    assert part1 is None and out1.shape == out.shape

@@ -258,9 +258,13 @@ def test_forward_takes_group_norm_statistics_from_the_producers(backend, request
     f, h, w, seed = gold["case"]
     x, t, y, hint = unet_inputs(SMALL_TEST_CONFIG, f, h, w, seed)
     dev = net.ctx.torch_device
-    n0 = net.ctx.lib.gn_fused_count(net.ctx.h)
+    n0, l0 = net.ctx.lib.gn_fused_count(net.ctx.h), net.ctx.lib.ln_fused_count(net.ctx.h)
     out = net(x.to(dev), t=t, y=y.to(dev), hint=hint.to(dev))
     fused = net.ctx.lib.gn_fused_count(net.ctx.h) - n0
+    ln_fused = net.ctx.lib.ln_fused_count(net.ctx.h) - l0
+    # the LayerNorm row coefficients / LIEM maps likewise come from the row statistics of proj_in / to_out + residual (every width of the
+    # reduced model is <= 640): 4 passes per SpatialTransformer, 3 per TemporalTransformer, 23 + 25 of them in the two nets
+    assert ln_fused == (0 if os.environ.get("STAR_NO_LNEPI") else 23 * 4 + 25 * 3), ln_fused
     assert rel_rms(out, gold["out"]) < REL_RMS[torch.float16][1]
     if os.environ.get("STAR_NO_GNEPI"):
         assert fused == 0

@@ -54,4 +54,11 @@ print({k: d[k] for k in ('value', 'ms_per_step')}, {k: d['roofline'].get(k) for 
 print(d.get('unet_kernel_ms') or d.get('breakdown'))
 PY
       ;;
+  8)  # LayerNorm row statistics in the producers' epilogues: new GPU tests, then the forward three ways on ONE box
+      timeout 900 python -m pytest tests/test_kernels.py tests/test_unet.py tests/test_parity_cfg4.py -m gpu -x -q -k "row_statistics or producer_epilogue or statistics_from or large_group_means or cfg4 or blocks_match or small_unet" 2>&1 | tail -6 > gpurun_out/r05_pytest_gpu_new3.txt
+      cat gpurun_out/r05_pytest_gpu_new3.txt
+      ( timeout 400 python tools/profile_forward.py 2>&1 | grep -v amdgpu.ids ) > gpurun_out/r05_forward_detail_f16_gn_ln_epi.txt 2>&1
+      ( STAR_NO_LNEPI=1 timeout 400 python tools/profile_forward.py 2>&1 | grep -v amdgpu.ids ) > gpurun_out/r05_forward_detail_f16_gn_epi_only.txt 2>&1
+      ( STAR_NO_LNEPI=1 STAR_NO_GNEPI=1 timeout 400 python tools/profile_forward.py 2>&1 | grep -v amdgpu.ids ) > gpurun_out/r05_forward_detail_f16_no_epi_stats.txt 2>&1
+      for f in gn_ln_epi gn_epi_only no_epi_stats; do echo "== $f"; head -2 gpurun_out/r05_forward_detail_f16_$f.txt; grep -E "group_norm|layer_norm" gpurun_out/r05_forward_detail_f16_$f.txt | head -2; done ;;
 esac
