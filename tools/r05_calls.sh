@@ -61,4 +61,20 @@ PY
       ( STAR_NO_LNEPI=1 timeout 400 python tools/profile_forward.py 2>&1 | grep -v amdgpu.ids ) > gpurun_out/r05_forward_detail_f16_gn_epi_only.txt 2>&1
       ( STAR_NO_LNEPI=1 STAR_NO_GNEPI=1 timeout 400 python tools/profile_forward.py 2>&1 | grep -v amdgpu.ids ) > gpurun_out/r05_forward_detail_f16_no_epi_stats.txt 2>&1
       for f in gn_ln_epi gn_epi_only no_epi_stats; do echo "== $f"; head -2 gpurun_out/r05_forward_detail_f16_$f.txt; grep -E "group_norm|layer_norm" gpurun_out/r05_forward_detail_f16_$f.txt | head -2; done ;;
+  9)  # closing evidence (one box): the whole GPU suite with its parity lines, smoke, the bench line (per-family table from the warm-up
+      # clip, power sampled live, operand sweep + live skeleton ceiling, CPU baseline), the same command under rocprofv3 --kernel-trace
+      # --stats, then the other configurations on the final tree
+      O=gpurun_out/r05z; mkdir -p $O
+      ( time timeout 1500 python -m pytest tests -m gpu -q -x -s 2>&1 | grep -v amdgpu.ids | grep -E "dB|rel rms|relative rms|passed|failed|error|skipped" ) > $O/pytest_gpu_final.txt 2>&1
+      tail -4 $O/pytest_gpu_final.txt
+      timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee $O/smoke.txt
+      timeout 900 python bench.py --steps 1 --warmup 1 > $O/bench_final_f16_n1.json 2> $O/bench.err
+      head -c 300 $O/bench_final_f16_n1.json; echo
+      R=${GRAFT_REPO_ROOT:-/root/repo}; ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_bench &&
+        timeout 700 rocprofv3 --kernel-trace --stats -d /tmp/prof_bench -o b --output-format csv -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-operand-sweep > $R/$O/bench_final_rocprof_f16_n1.json 2> $R/$O/rocprof.err;
+        f=$(find /tmp/prof_bench -name "*kernel_stats.csv" | head -1); cp "$f" $R/$O/bench_final_kernel_stats.csv 2>/dev/null )
+      head -6 $O/bench_final_kernel_stats.csv
+      timeout 400 python bench.py --dtype bf16 --steps 1 --warmup 0 --no-cpu-baseline --no-operand-sweep > $O/bench_bf16_n1.json 2>> $O/bench.err; head -c 200 $O/bench_bf16_n1.json; echo
+      timeout 400 python bench.py --config cfg3 --steps 1 --warmup 0 --no-cpu-baseline --no-operand-sweep > $O/bench_cfg3_fast_f16_n1.json 2>> $O/bench.err; head -c 200 $O/bench_cfg3_fast_f16_n1.json; echo
+      timeout 1100 python bench.py --config cfg4 --steps 1 --warmup 0 --no-cpu-baseline --no-operand-sweep > $O/bench_cfg4_50eval_f16_n1.json 2>> $O/bench.err; head -c 200 $O/bench_cfg4_50eval_f16_n1.json; echo ;;
 esac
