@@ -226,8 +226,8 @@ def test_group_norm_fold_with_large_group_means(backend, dtype, request):
     """TemporalTransformer.norm folded into proj_in (norm.h: gn_fold_weights_kernel; unet_v2v.py:1002-1005,1052-1060) on an input
     whose groups sit at |mean| = 10-40 x their spread, with non-trivial gamma / beta: the fold subtracts the group means with the
     ROUNDED weights, so its error scales with |x - mean| like the unfolded norm + Linear (STAR_NO_GNFOLD=1), not with |x|.  Measured on
-    the transformer BRANCH (out - x) against the fp32 oracle on the same 16-bit-exact input.  (The plain fold W' = round(W a),
-    b' = b + W b_c fails this test: 3.4e-2 in f16.)"""
+    the transformer BRANCH (out - x) against the fp32 oracle on the same 16-bit-exact input.  (Measured: 1.2e-3 in f16 for this fold and for the unfolded pair,
+    6.4e-3 for the plain fold W' = round(W a), b' = b + W b_c, which fails the bound; bf16 9.5e-3.)"""
     emu = request.getfixturevalue("emu_lib") if backend == "emu" else None
     ctx = make_ctx(backend, dtype, emu)
     b = torch.load(os.path.join(GOLD, "blocks.pt"))["tt_64_128"]
@@ -244,7 +244,7 @@ def test_group_norm_fold_with_large_group_means(backend, dtype, request):
     branch, rbranch = y - x, ref - x
     assert float(rbranch.abs().mean()) > 10 * float(x.abs().mean()) * 2.0 ** (-8 if dtype == torch.bfloat16 else -11)   # the branch is not lost in the residual's rounding
     e = rel_rms(branch, rbranch)
-    assert e < (6e-3 if dtype == torch.float16 else 5e-2), e
+    assert e < (2.5e-3 if dtype == torch.float16 else 2e-2), e
     ctx.close()
 
 

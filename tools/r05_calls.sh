@@ -77,4 +77,22 @@ PY
       timeout 400 python bench.py --dtype bf16 --steps 1 --warmup 0 --no-cpu-baseline --no-operand-sweep > $O/bench_bf16_n1.json 2>> $O/bench.err; head -c 200 $O/bench_bf16_n1.json; echo
       timeout 400 python bench.py --config cfg3 --steps 1 --warmup 0 --no-cpu-baseline --no-operand-sweep > $O/bench_cfg3_fast_f16_n1.json 2>> $O/bench.err; head -c 200 $O/bench_cfg3_fast_f16_n1.json; echo
       timeout 1100 python bench.py --config cfg4 --steps 1 --warmup 0 --no-cpu-baseline --no-operand-sweep > $O/bench_cfg4_50eval_f16_n1.json 2>> $O/bench.err; head -c 200 $O/bench_cfg4_50eval_f16_n1.json; echo ;;
+  10) # PMC passes (one counter group per run, kernel trace only) on the torch-free harness: attention traffic + MFMA / VALU / LDS / wait
+      # counters of the dominant kernels at their cfg2 shapes
+      R=${GRAFT_REPO_ROOT:-/root/repo}; cd /tmp && export TMPDIR=/tmp
+      for pmc in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES" "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_WAVE_CYCLES" \
+                 "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES" "GRBM_GUI_ACTIVE"; do
+        tag=$(echo "$pmc" | cut -d' ' -f1)
+        timeout 150 rocprofv3 --kernel-trace --pmc $pmc -d $R/gpurun_out/r05_pmc_$tag -- \
+          $R/tools/cbench/cbench $R/tools/bench/libstar_hip_bench.so f16 $R/tools/cbench/pmc_shapes.txt 1 > $R/gpurun_out/r05_pmc_$tag.log 2>&1
+      done
+      python $R/tools/pmc_db_summary.py $R/gpurun_out/r05_pmc_FETCH_SIZE $R/gpurun_out/r05_pmc_WRITE_SIZE $R/gpurun_out/r05_pmc_SQ_INSTS_VALU $R/gpurun_out/r05_pmc_SQ_WAIT_INST_ANY $R/gpurun_out/r05_pmc_SQ_LDS_BANK_CONFLICT $R/gpurun_out/r05_pmc_GRBM_GUI_ACTIVE > $R/gpurun_out/r05_pmc_kernels.txt 2>&1
+      head -60 $R/gpurun_out/r05_pmc_kernels.txt
+      # one bench clip each way on this box: statistics in the epilogues off (the round-4 forward) / on
+      cd $R
+      for mode in off on; do
+        if [ $mode = off ]; then export STAR_NO_GNEPI=1 STAR_NO_LNEPI=1; else unset STAR_NO_GNEPI STAR_NO_LNEPI; fi
+        timeout 400 python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-operand-sweep 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().split('\n')[-1]); print('[epilogue statistics $mode] value', round(d['value'],4), 'frames/s, ms_per_step', round(d['ms_per_step'],1), ', L0 attention', round(d['roofline']['achieved'],1), 'TF/s')"
+      done > gpurun_out/r05_same_box_bench_stats_off_on.txt 2>&1
+      cat gpurun_out/r05_same_box_bench_stats_off_on.txt ;;
 esac
