@@ -25,7 +25,12 @@ typedef struct star_ctx star_ctx;
 
 enum { STAR_F16 = 0, STAR_BF16 = 1, STAR_F32 = 2 };
 
-/* A-operand gather modes of star_gemm (see star_amd/csrc/gemm.h) */
+/* A-operand gather modes of star_gemm (see star_amd/csrc/gemm.h).  Weight matrices W are [N][K], K contiguous:
+ *   STAR_A_PLAIN      K = the Linear's input width;
+ *   STAR_A_CONV3X3 / STAR_A_CONV3X3_UP   K = 9 * Cin (Cin % 64 == 0) with K index ((c / 64) * 9 + tap) * 64 + c % 64, tap = ky * 3 + kx: the nine
+ *                     taps of a 64-channel block are adjacent (the kernel walks them back to back so that their shifted re-reads of the same
+ *                     input lines hit the L2); star_amd.lib.pack_conv3x3_weight converts nn.Conv2d's [Cout, Cin, 3, 3];
+ *   STAR_A_TCONV3     K = 3 * Cin with K index tap * Cin + c (nn.Conv3d (3,1,1)'s [Cout, Cin, 3, 1, 1], tap-major). */
 enum { STAR_A_PLAIN = 0, STAR_A_CONV3X3 = 1, STAR_A_CONV3X3_UP = 2, STAR_A_TCONV3 = 3 };
 /* epilogue flags of star_gemm */
 enum { STAR_EPI_BIAS = 1, STAR_EPI_RES = 2, STAR_EPI_GEGLU = 4, STAR_EPI_OUT_F32 = 8,

@@ -279,8 +279,19 @@ gemm_kernel(const GemmParams p) {
   };
   auto stage_post = [&]() STAR_ALWAYS_INLINE {
     if constexpr (AMODE != A_PLAIN) {
-      c0 += BK;
-      if (c0 >= p.Cin) { c0 = 0; ++tap; }
+      // 3x3 convs: the K loop walks the nine TAPS inside a 64-channel block (K index = (c / 64, tap, c % 64), the weights are packed
+      // to match): consecutive K tiles re-read the same 128-byte input lines shifted by one pixel / one image row, which the XCD's L2 still
+      // holds.  With the channel blocks inside a tap (the order until round 5) a line came back five K tiles x 32 workgroups later: every
+      // tap was fetched from beyond the L2, 5.0 GB per level-0 launch against 0.54 GB of input (profiles/r05_pmc_kernels.txt);
+      // -7.8 % / -3.8 % / -1.4 % at the 320 / 640 / 1280-wide levels (profiles/r05_cbench_conv_korder.txt).  The temporal conv's taps are
+      // whole frames apart (no reuse within reach of any cache): it keeps tap-major order (channel-major measured +1-3 % slower).
+      if constexpr (AMODE == A_TCONV3) {
+        c0 += BK;
+        if (c0 >= p.Cin) { c0 = 0; ++tap; }
+      } else {
+        ++tap;
+        if (tap >= 9) { tap = 0; c0 += BK; }
+      }
     }
   };
   // LDS of the 2-stage loop: [A stage 0 | A stage 1 | W stage 0 | W stage 1] -- with the stage a compile-time constant of the
@@ -380,7 +391,11 @@ gemm_kernel(const GemmParams p) {
 #pragma unroll
       for (int i = 0; i < LW0; ++i) glds16_su(w_tile + (size_t)s_ * 64, pw_off[i], wbuf + (size_t)(wv + NWV * i) * 1024);
       if (WX > 0 && wextra) glds16_su(w_tile + (size_t)s_ * 64, pw_off[LW0], wbuf + (size_t)(wv + NWV * LW0) * 1024);
-      if constexpr (AMODE != A_PLAIN) { pc0 += 32; if (pc0 >= p.Cin) { pc0 = 0; ++ptap; } }
+      if constexpr (AMODE == A_TCONV3) { pc0 += 32; if (pc0 >= p.Cin) { pc0 = 0; ++ptap; } }
+      else if constexpr (AMODE != A_PLAIN) {   // 3x3 convs: (c / 64, tap, c % 64) -- two 32-deep steps per (block, tap)
+        pc0 += 32;
+        if ((pc0 & 63) == 0) { pc0 -= 64; ++ptap; if (ptap >= 9) { ptap = 0; pc0 += 64; } }
+      }
     };
     // wait until at most `steps_in_flight` K steps of this wave's DMA are outstanding
     auto wait_steps = [&](int steps_in_flight) {

@@ -52,12 +52,17 @@ static int launch_gemm_f(Ctx* ctx, const GemmArgs& a) {
   }
   if (a.gn_partial) {   // the caller (launch_gemm) has checked mode and epilogue; the flavour exists for GNS tiles only
     if constexpr (GNS && !F32OUT) {
+      // (the scheduled one-wave-per-SIMD tile has the flavour without a residual only: with the residual's registers beside its 256
+      // accumulators the bf16 instantiation spilled one register; launch_gemm drops the request there)
+      if constexpr (SCHED != 0) { if (res) return ctx->fail("gemm: the scheduled tile has no GroupNorm-statistics flavour with a residual"); }
+#define STAR_GEMM_GO_GN(MODE) do { if constexpr (SCHED == 0) { if (res) STAR_GEMM_GO(MODE, 17); else STAR_GEMM_GO(MODE, 16); } else STAR_GEMM_GO(MODE, 16); } while (0)
       switch (a.mode) {
-        case A_PLAIN: if (res) STAR_GEMM_GO(A_PLAIN, 17); else STAR_GEMM_GO(A_PLAIN, 16); break;
-        case A_CONV3X3: if (res) STAR_GEMM_GO(A_CONV3X3, 17); else STAR_GEMM_GO(A_CONV3X3, 16); break;
-        case A_TCONV3: if (res) STAR_GEMM_GO(A_TCONV3, 17); else STAR_GEMM_GO(A_TCONV3, 16); break;
+        case A_PLAIN: STAR_GEMM_GO_GN(A_PLAIN); break;
+        case A_CONV3X3: STAR_GEMM_GO_GN(A_CONV3X3); break;
+        case A_TCONV3: STAR_GEMM_GO_GN(A_TCONV3); break;
         default: return ctx->fail("gemm: no GroupNorm-statistics flavour of this mode");
       }
+#undef STAR_GEMM_GO_GN
       if (a.gn_done) *a.gn_done = true;
       return 0;
     } else return ctx->fail("gemm: this tile has no GroupNorm-statistics flavour");
@@ -162,7 +167,7 @@ static int launch_gemm(Ctx* ctx, const GemmArgs& a) {
   }
   // GroupNorm statistics in the epilogue: the flavour exists for tiles 2, 3 and 17 on plain / 3x3 / temporal-conv layers with the
   // bias (+ residual) 16-bit epilogue; elsewhere the request is dropped (gn_done stays false: the consumer runs its own pass)
-  if (a.gn_partial && (!(tile == 2 || tile == 3 || tile == 17) || !(a.mode == A_PLAIN || a.mode == A_CONV3X3 || a.mode == A_TCONV3) ||
+  if (a.gn_partial && (!(tile == 2 || tile == 3 || tile == 17) || (tile == 17 && (a.epi & EPI_RES)) || !(a.mode == A_PLAIN || a.mode == A_CONV3X3 || a.mode == A_TCONV3) ||
                        (a.epi & (EPI_OUT_F32 | EPI_ROWAFF | EPI_GELU_TANH | EPI_GEGLU)) || (a.N & 7))) {
     GemmArgs b = a;
     b.gn_partial = nullptr;

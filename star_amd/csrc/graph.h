@@ -81,21 +81,25 @@ struct Builder {
     const HostTensor* w = get(p + ".weight");
     if (!w) return l;
     const int N0 = (int)w->shape[0], C = (int)w->shape[1];
+    if (C % 64) { if (err.empty()) err = "conv3x3: input channels must be a multiple of 64 (" + p + ")"; return l; }
     const int N = (N0 + pad_n_to - 1) / pad_n_to * pad_n_to;   // zero rows up to a multiple (fp32-out GEMMs need N % 4 == 0)
     if (N != N0) {
       std::vector<float> r((size_t)N * 9 * C, 0.f), rb(N, 0.f);
       const HostTensor* bb = get(p + ".bias");
       if (!bb) return l;
-      for (int n = 0; n < N0; ++n) { rb[n] = bb->data[n]; for (int c = 0; c < C; ++c) for (int t = 0; t < 9; ++t) r[((size_t)n * 9 + t) * C + c] = w->data[((size_t)n * C + c) * 9 + t]; }
+      for (int n = 0; n < N0; ++n) { rb[n] = bb->data[n]; for (int c = 0; c < C; ++c) for (int t = 0; t < 9; ++t) r[(size_t)n * 9 * C + conv_k(c, t)] = w->data[((size_t)n * C + c) * 9 + t]; }
       l.N = N; l.K = 9 * C; l.w = upload_T(r); l.b = upload_f32(rb);
       return l;
     }
     std::vector<float> r((size_t)N * 9 * C);
     for (int n = 0; n < N; ++n) for (int c = 0; c < C; ++c) for (int t = 0; t < 9; ++t)
-      r[((size_t)n * 9 + t) * C + c] = w->data[((size_t)n * C + c) * 9 + t];
+      r[(size_t)n * 9 * C + conv_k(c, t)] = w->data[((size_t)n * C + c) * 9 + t];
     l.N = N; l.K = 9 * C; l.w = upload_T(r); l.b = bias(p + ".bias");
     return l;
   }
+  // K index of (input channel c, tap t) of a 3x3 conv: 64-channel blocks outermost, the nine taps inside a block (gemm.h: the K loop
+  // walks the taps of one block back to back, so that their shifted re-reads of the same input lines hit the L2); Cin % 64 == 0
+  static size_t conv_k(int c, int t) { return ((size_t)(c >> 6) * 9 + t) * 64 + (c & 63); }
   // stem-like Conv2d 3x3 with tiny C (4): [N, C, 3, 3] -> [N][64] columns tap*C + c, zero padded (pairs with stem_im2col)
   LinW conv3x3_im2col64(const std::string& p) {
     LinW l;

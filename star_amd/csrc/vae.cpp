@@ -181,7 +181,7 @@ int vae_build(Ctx* ctx, const VaeCfg& cfg) {
         for (int m = 0; m < L2; ++m) {
           const float qv = qw->data[(size_t)o * L2 + m];
           rb[o] += qv * bb->data[m];
-          for (int c = 0; c < C; ++c) for (int t = 0; t < 9; ++t) r[((size_t)o * 9 + t) * C + c] += qv * w->data[((size_t)m * C + c) * 9 + t];
+          for (int c = 0; c < C; ++c) for (int t = 0; t < 9; ++t) r[(size_t)o * 9 * C + Builder::conv_k(c, t)] += qv * w->data[((size_t)m * C + c) * 9 + t];   // K order of the 3x3 modes (graph.h: conv_k)
         }
       }
       M->e_conv_out.N = L2; M->e_conv_out.K = 9 * C; M->e_conv_out.w = b.upload_T(r); M->e_conv_out.b = b.upload_f32(rb);

@@ -169,6 +169,14 @@ def device_index(device):
     return int(device)
 
 
+def pack_conv3x3_weight(w):
+    """[Cout, Cin, 3, 3] -> the [Cout, 9 * Cin] matrix star_gemm's 3x3 modes expect: K index = (c // 64, tap, c % 64), i.e. 64-channel
+    blocks outermost and the nine taps (ky * 3 + kx) inside a block; Cin % 64 == 0."""
+    Cout, Cin = w.shape[:2]
+    assert Cin % 64 == 0 and tuple(w.shape[2:]) == (3, 3)
+    return w.reshape(Cout, Cin // 64, 64, 9).permute(0, 1, 3, 2).reshape(Cout, 9 * Cin).contiguous()
+
+
 class Context:
     """One star_ctx: a device, a compute dtype (fp16/bf16), a stream, a workspace pool."""
 

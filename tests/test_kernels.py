@@ -149,7 +149,7 @@ def test_conv3x3_variants(ctx, dtype, NB, Cin, H, Wd, Cout):
     x = torch.randn(NB, Cin, H, Wd, generator=g).to(dtype)
     w = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)).to(dtype)
     b = torch.randn(Cout, generator=g)
-    wp = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous()
+    wp = L.pack_conv3x3_weight(w)   # K index (c // 64, tap, c % 64): the kernel walks the nine taps of a 64-channel block back to back
     xr, wpd, bd = dev(ctx, nhwc_rows(x)), dev(ctx, wp), dev(ctx, b)
     # ResBlock / Upsample conv: 3x3 stride 1 pad 1 (unet_v2v.py:612,639)
     ref = F.conv2d(x.float(), w.float(), b, padding=1)
@@ -257,7 +257,7 @@ def test_gemm_tail_split_is_bit_identical(ctx, dtype):
     x = torch.randn(NB, Cin, H, Wd, generator=g).to(dtype)
     w = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)).to(dtype)
     b = torch.randn(Cout, generator=g)
-    wp = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous()
+    wp = L.pack_conv3x3_weight(w)   # K index (c // 64, tap, c % 64): the kernel walks the nine taps of a 64-channel block back to back
     xr, wpd, bd = dev(ctx, nhwc_rows(x)), dev(ctx, wp), dev(ctx, b)
     ref = F.conv2d(x.float(), w.float(), b, padding=1)
     whole = ctx.gemm(xr, wpd, bias=bd, mode=L.A_CONV3X3, conv=(NB, H, Wd, Cin, H, Wd, 1, 1, 1), force_tile=1)
@@ -267,7 +267,7 @@ def test_gemm_tail_split_is_bit_identical(ctx, dtype):
     # the same conv 64 -> 320 channels: 256 x 320 tiles (one tile column)
     w3 = (torch.randn(320, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)).to(dtype)
     b3 = torch.randn(320, generator=g)
-    w3d, b3d = dev(ctx, w3.permute(0, 2, 3, 1).reshape(320, 9 * Cin).contiguous()), dev(ctx, b3)
+    w3d, b3d = dev(ctx, L.pack_conv3x3_weight(w3)), dev(ctx, b3)
     whole = ctx.gemm(xr, w3d, bias=b3d, mode=L.A_CONV3X3, conv=(NB, H, Wd, Cin, H, Wd, 1, 1, 1), force_tile=2)
     split = ctx.gemm(xr, w3d, bias=b3d, mode=L.A_CONV3X3, conv=(NB, H, Wd, Cin, H, Wd, 1, 1, 1), force_tile=1008)
     assert torch.equal(whole, split)
@@ -325,7 +325,7 @@ def test_conv_scheduled_tile(ctx, dtype, NB, Cin, H, Wd, Cout):
     x = torch.randn(NB, Cin, H, Wd, generator=g).to(dtype)
     w = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)).to(dtype)
     b = torch.randn(Cout, generator=g)
-    wp = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous()
+    wp = L.pack_conv3x3_weight(w)   # K index (c // 64, tap, c % 64): the kernel walks the nine taps of a 64-channel block back to back
     xr, wpd, bd = dev(ctx, nhwc_rows(x)), dev(ctx, wp), dev(ctx, b)
     ref = F.conv2d(x.float(), w.float(), b, padding=1)
     out = ctx.gemm(xr, wpd, bias=bd, mode=L.A_CONV3X3, conv=(NB, H, Wd, Cin, H, Wd, 1, 1, 1), force_tile=17)
