@@ -95,4 +95,16 @@ PY
         timeout 400 python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-operand-sweep 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().split('\n')[-1]); print('[epilogue statistics $mode] value', round(d['value'],4), 'frames/s, ms_per_step', round(d['ms_per_step'],1), ', L0 attention', round(d['roofline']['achieved'],1), 'TF/s')"
       done > gpurun_out/r05_same_box_bench_stats_off_on.txt 2>&1
       cat gpurun_out/r05_same_box_bench_stats_off_on.txt ;;
+  11) # final tree (channel-major 3x3 convs): the whole GPU suite, smoke, the forward table, the bench line and the same command under rocprofv3
+      O=gpurun_out/r05f; mkdir -p $O
+      ( time timeout 1500 python -m pytest tests -m gpu -q -x -s 2>&1 | grep -v amdgpu.ids | grep -E "dB|rel rms|relative rms|passed|failed|error|skipped" ) > $O/pytest_gpu_final.txt 2>&1
+      tail -4 $O/pytest_gpu_final.txt
+      timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee $O/smoke.txt
+      ( timeout 400 python tools/profile_forward.py 2>&1 | grep -v amdgpu.ids ) > $O/forward_detail_f16_final.txt 2>&1; head -2 $O/forward_detail_f16_final.txt
+      timeout 900 python bench.py --steps 1 --warmup 1 > $O/bench_final_f16_n1.json 2> $O/bench.err
+      head -c 300 $O/bench_final_f16_n1.json; echo
+      R=${GRAFT_REPO_ROOT:-/root/repo}; ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_bench &&
+        timeout 700 rocprofv3 --kernel-trace --stats -d /tmp/prof_bench -o b --output-format csv -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-operand-sweep > $R/$O/bench_final_rocprof_f16_n1.json 2> $R/$O/rocprof.err;
+        f=$(find /tmp/prof_bench -name "*kernel_stats.csv" | head -1); cp "$f" $R/$O/bench_final_kernel_stats.csv 2>/dev/null )
+      head -4 $O/bench_final_kernel_stats.csv; head -c 200 $O/bench_final_rocprof_f16_n1.json; echo ;;
 esac
