@@ -5,7 +5,10 @@
     A-stationary GEMM + star_temporal_attn_fwd;
   * gathered modes (3x3 conv, stride-2 Downsample, temporal conv) under the tail split                    -- bit for bit, unsplit tile 1;
   * the A-stationary K = 320 kernel (gemm_as.h)                                                           -- <= 1 ulp of tile 1;
-  * flash_attn_v5_kernel / temporal_attn_kernel on ragged lengths, shared K / V, strided views            -- fp32 softmax, <= 4 ulp.
+  * flash_attn_v5_kernel / temporal_attn_kernel on ragged lengths, shared K / V, strided views            -- fp32 softmax, <= 4 ulp;
+  * round 5: the statistics flavours of the epilogue (gemm.h EPIF 16 / 17 / 32 / 33: star_gemm_gn, star_gemm_rowstats) with random
+    (frames, pixels, widths, tiles, residual)  -- output bit for bit against star_gemm, partials against float64 sums of the stored
+    outputs, GroupNorm / LayerNorm coefficients from the partials against the stand-alone kernels.
 The parametrised cases of tests/test_kernels.py are hand-picked edges; this draws the shapes.  `python tools/fuzz_emu.py --cases 40
 --seed 1 > profiles/rNN_fuzz_emu.txt`.  Test tooling: the product never loads the emulator."""
 import argparse
@@ -206,18 +209,66 @@ def fuzz_tattn(ctx, dtype, rng, budget):
     return bool(torch.isfinite(out).all()) and err <= tol, f"tattn F={Fr} HW={HW} heads={heads} err={err:.2e} tol={tol:.2e}"
 
 
+def fuzz_epi_stats(ctx, dtype, rng, budget):
+    """GroupNorm partials / LayerNorm row statistics written by the producer's epilogue (round 5)"""
+    import torch.nn.functional as F
+    Fr, HW = rng.randint(1, 5), rng.randint(3, 130)
+    M = Fr * HW
+    K = 64 * rng.randint(1, 3)
+    kind = rng.choice(["gn", "gn", "ln"])
+    tile = rng.choice([2, 3] if kind == "ln" else [2, 3, 17])
+    N = 64 * rng.randint(1, 6) if kind == "gn" else 8 * rng.randint(2, 60)
+    g = torch.Generator().manual_seed(rng.randint(0, 1 << 30))
+    a = dev(ctx, torch.randn(M, K, generator=g).to(dtype))
+    w = dev(ctx, (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dtype))
+    b = dev(ctx, torch.randn(N, generator=g) + 2.0)
+    res = dev(ctx, torch.randn(M, N, generator=g).to(dtype)) if (rng.random() < 0.5 and tile != 17) else None
+    plain = ctx.gemm(a, w, bias=b, res=res, force_tile=tile)
+    tag = f"epi-stats {kind} tile={tile} F={Fr} HW={HW} N={N} K={K} res={res is not None}"
+    if kind == "gn":
+        out, part = ctx.gemm(a, w, bias=b, res=res, force_tile=tile, gn_partial=True)
+        if part is None or not torch.equal(out, plain):
+            return False, tag
+        o = out.double().cpu()
+        pad = (-M) % 32
+        o2 = torch.cat([o, torch.zeros(pad, N, dtype=torch.float64)]) if pad else o
+        o2 = o2.reshape(-1, 32, N // 2, 2)
+        want = torch.stack([o2.sum(dim=(1, 3)), (o2 * o2).sum(dim=(1, 3))], dim=-1)
+        ok = (part.double().cpu() - want).abs().max().item() <= 3e-5 * (want[..., 1].abs().max().item() + 1.0)
+        gam, bet = torch.randn(N, generator=g), torch.randn(N, generator=g)
+        for rps in (HW, M):
+            y = ctx.group_norm_from_partials(out, part, dev(ctx, gam), dev(ctx, bet), rps, eps=1e-5, silu=False).float().cpu()
+            y0 = ctx.group_norm(out, dev(ctx, gam), dev(ctx, bet), rps, eps=1e-5, silu=False).float().cpu()
+            ok = ok and (y - y0).abs().max().item() <= (3e-2 if dtype == torch.bfloat16 else 4e-3) * (1 + y0.abs().max().item())
+        return ok, tag
+    out, part = ctx.gemm(a, w, bias=b, res=res, force_tile=tile, row_stats=True)
+    if part is None:
+        return False, tag + " (no partials)"
+    if not torch.equal(out, plain):
+        return False, tag
+    o = out.double().cpu()
+    p = part.double().cpu()
+    ok = (p[..., 0].sum(1) - o.sum(1)).abs().max().item() <= 2e-5 * (o.abs().sum(1).max().item() + 1)
+    ok = ok and (p[..., 1].sum(1) - (o * o).sum(1)).abs().max().item() <= 3e-5 * ((o * o).sum(1).max().item() + 1)
+    ok = ok and torch.equal(p[..., 2].max(1).values, o.max(1).values)
+    ab = ctx.layer_norm_rowab_from_partials(part, N).cpu()
+    ab0 = ctx.layer_norm_rowab(out).cpu()
+    ok = ok and ((ab - ab0).abs() / (ab0.abs() + 1e-3)).max().item() <= 3e-3
+    return ok, tag
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=30)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--budget", type=float, default=6e7, help="M*N*K bound of a GEMM case (the emulator runs ~1e7 MACs per second)")
-    ap.add_argument("--kinds", default="persist,strided,tq,conv,astat,attn,tattn")
+    ap.add_argument("--kinds", default="persist,strided,tq,conv,astat,attn,tattn,epistats")
     args = ap.parse_args()
     emu = L.Library(os.path.join(ROOT, "tools", "hostemu", "libstar_emu.so"))
     assert emu.is_hostemu
     rng = random.Random(args.seed)
     fns = {"persist": fuzz_persist, "strided": fuzz_strided_persist, "tq": fuzz_tq, "conv": fuzz_conv_split, "astat": fuzz_astat,
-           "attn": fuzz_attn, "tattn": fuzz_tattn}
+           "attn": fuzz_attn, "tattn": fuzz_tattn, "epistats": fuzz_epi_stats}
     kinds = [k for k in args.kinds.split(",") if k]
     bad = 0
     t0 = time.time()
