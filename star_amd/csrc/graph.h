@@ -75,7 +75,7 @@ struct Builder {
     if (has_bias) l.b = bias(p + ".bias");
     return l;
   }
-  // Conv2d 3x3 [N, C, 3, 3] -> [N][tap][C] (K = 9C, tap-major), tap = ky*3 + kx
+  // Conv2d 3x3 [N, C, 3, 3] -> [N][C / 64][tap][64] (K = 9C: the nine taps of a 64-channel block adjacent, conv_k below), tap = ky*3 + kx
   LinW conv3x3(const std::string& p, int pad_n_to = 1) {
     LinW l;
     const HostTensor* w = get(p + ".weight");

@@ -107,4 +107,13 @@ PY
         timeout 700 rocprofv3 --kernel-trace --stats -d /tmp/prof_bench -o b --output-format csv -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-operand-sweep > $R/$O/bench_final_rocprof_f16_n1.json 2> $R/$O/rocprof.err;
         f=$(find /tmp/prof_bench -name "*kernel_stats.csv" | head -1); cp "$f" $R/$O/bench_final_kernel_stats.csv 2>/dev/null )
       head -4 $O/bench_final_kernel_stats.csv; head -c 200 $O/bench_final_rocprof_f16_n1.json; echo ;;
+  12) # the cfg3 chunk-loop golden on hardware; the level-0 3x3 conv's HBM-side traffic after the K-order change; the tile sweep on the final tree
+      ( timeout 600 python -m pytest tests/test_parity_cfg3.py -m gpu -q -x -s 2>&1 | grep -v amdgpu.ids | grep -E "dB|passed|failed|error|skipped|Error" ) > gpurun_out/r05_pytest_parity_cfg3.txt 2>&1
+      cat gpurun_out/r05_pytest_parity_cfg3.txt
+      R=${GRAFT_REPO_ROOT:-/root/repo}; printf 'conv 32 122 216 320 320 2\nconv 32 62 108 640 640 2\n' > /tmp/convs.txt
+      ( cd /tmp && export TMPDIR=/tmp && for pmc in FETCH_SIZE WRITE_SIZE; do
+          timeout 100 rocprofv3 --kernel-trace --pmc $pmc -d $R/gpurun_out/r05_pmc_conv_$pmc -- $R/tools/cbench/cbench $R/tools/bench/libstar_hip_bench.so f16 /tmp/convs.txt 1 > $R/gpurun_out/r05_pmc_conv_$pmc.log 2>&1; done )
+      python tools/pmc_db_summary.py gpurun_out/r05_pmc_conv_FETCH_SIZE gpurun_out/r05_pmc_conv_WRITE_SIZE > gpurun_out/r05_pmc_conv_after.txt 2>&1; cat gpurun_out/r05_pmc_conv_after.txt
+      timeout 90 ./tools/cbench/cbench tools/bench/libstar_hip_bench.so f16 tools/cbench/cfg2_tile_sweep.txt 6 > gpurun_out/r05_cbench_tile_sweep_final.txt 2>&1
+      grep -v differ gpurun_out/r05_cbench_tile_sweep_final.txt | grep -E "conv|tile=0 " | cut -c1-110 ;;
 esac
