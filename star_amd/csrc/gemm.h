@@ -56,6 +56,11 @@ struct GemmParams {
   // (ln_parts = tiles_n * WN; every (row, part) is written exactly once)
   float* ln_partial;
   int ln_parts;
+  // A_TCONV3: t_walk > 0 (= tile rows per pixel block enumeration is frame-interleaved): consecutive tile rows of the walk are the SAME pixel
+  // block of consecutive frames, so the 32 workgroups an XCD runs at a time read each input frame tile three times within one
+  // round -- from the L2 -- instead of once per round of ~100 tiles from beyond it.  Set by the launcher when the launch covers
+  // whole frames (no tail split); 0 = row-major.
+  int t_walk;
 };
 
 // exact (erf) GELU, F.gelu default (unet_v2v.py:504): gelu(x) = max(x, 0) - |x| q(|x|), q(t) = 0.5 erfc(t / sqrt 2).
@@ -154,6 +159,25 @@ gemm_kernel(const GemmParams p) {
     const int rows = p.tiles_m - g * p.group_m < p.group_m ? p.tiles_m - g * p.group_m : p.group_m;
     tile_m = g * p.group_m + in % rows;
     tile_n = in / rows;
+  }
+  if constexpr (AMODE == A_TCONV3) {
+    if (p.t_walk > 0) {
+      // tile rows [s_f, s_{f+1}) with s_f = (f * HW) / BM start inside frame f; k = j * F + f enumerates (pixel block j, frame f) for the
+      // j every frame has; the frames with one tile row more come last
+      const int Fn = p.F, k = tile_m;
+      const int nmin = (int)(((long long)p.HW) / BM);          // every frame has nmin or nmin + 1 tile rows
+      if (k < nmin * Fn) {
+        const int j = k / Fn, f = k - j * Fn;
+        tile_m = (int)(((long long)f * p.HW) / BM) + j;
+      } else {
+        int r = k - nmin * Fn, last = p.tiles_m - 1;
+        for (int f = 0; f < Fn && r >= 0; ++f) {
+          const int s0 = (int)(((long long)f * p.HW) / BM), s1 = f + 1 < Fn ? (int)(((long long)(f + 1) * p.HW) / BM) : p.tiles_m;
+          for (int e = nmin; e < s1 - s0 && r >= 0; ++e) { if (r == 0) last = s0 + e; --r; }
+        }
+        tile_m = last;
+      }
+    }
   }
   tile_m += p.m_off / BM;   // (a multiple of BM by construction; added to the tile index so that m0 stays a provable multiple of BM --
                             // as "p.m_off + tile_m * BM" the 256 x 320 and 128 x 320 residual flavours spilled 1-5 registers)

@@ -184,6 +184,22 @@ def test_temporal_conv(ctx, dtype, Fr, H, Wd, C):
     assert_close(out, ref, dtype, what="tconv")
 
 
+@pytest.mark.parametrize("Fr,HW,C,tile", [(3, 300, 64, 3), (4, 300, 64, 2), (5, 257, 128, 3), (2, 700, 256, 17), (33, 130, 64, 3)])
+def test_temporal_conv_frame_interleaved_walk(ctx, dtype, Fr, HW, C, tile):
+    """A_TCONV3 with frames of at least one tile row: the launcher walks the tile rows frame-interleaved (gemm.h t_walk: the same pixel
+    block of consecutive frames back to back, so that an XCD's workgroups share the input frame tiles in its L2).  Every tile row is
+    still computed exactly once, whatever the ratio of frame length to tile height: the result matches torch's Conv3d (3,1,1)."""
+    g = torch.Generator().manual_seed(Fr * HW + tile)
+    x = torch.randn(1, C, Fr, HW, 1, generator=g).to(dtype)
+    w = (torch.randn(C, C, 3, 1, 1, generator=g) / math.sqrt(3 * C)).to(dtype)
+    b = torch.randn(C, generator=g)
+    ref = F.conv3d(x.float(), w.float(), b, padding=(1, 0, 0))[0].permute(1, 2, 3, 0).reshape(-1, C)
+    a = x[0].permute(1, 2, 3, 0).reshape(-1, C).contiguous()
+    wp = w[:, :, :, 0, 0].permute(0, 2, 1).reshape(C, 3 * C).contiguous()
+    out = ctx.gemm(dev(ctx, a), dev(ctx, wp), bias=dev(ctx, b), mode=L.A_TCONV3, temporal=(Fr, HW, C), force_tile=tile)
+    assert_close(out, ref, dtype, what="tconv, frame-interleaved walk")
+
+
 @pytest.mark.parametrize("M,N,K,wgs", [(515, 512, 256, 0), (300, 264, 64, 0), (700, 600, 192, 2), (257, 1288, 128, 3), (1030, 256, 448, 1), (64, 8, 64, 0), (700, 576, 128, 2), (700, 600, 64, 2),
                                         (2100, 1920, 640, 8)])
 def test_gemm_persistent_tile(ctx, dtype, M, N, K, wgs):
