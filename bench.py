@@ -32,6 +32,8 @@ sys.path.insert(0, ROOT)
 UNET_FWD_TFLOP_CFG2 = 572.3         # one UNet+ControlNet forward, 32 f, latent 122x216
 VAE_TFLOP_PER_FRAME = 8.4 + 20.8    # encode + decode at 976x1728 (estimate)
 PEAK_BF16_MFMA = 2.5e15             # dense, MI355X_MICROARCH.md
+PEAK_HBM = 8.0e12                   # HBM3E, MI355X_MICROARCH.md
+ROOFLINE_KERNEL = "flash_attn_v5_kernel"   # the kernel the top-level roofline object describes (star_amd/csrc/attn5.h, AttnArgs::variant 9)
 
 # BASELINE.json configs[0..3] (configs[4], CogVideoX, is out of scope: SURVEY.md section 8f).  fwd_tflop = one UNet+ControlNet
 # forward on one chunk (FlopCounterMode on the reference); vae_scale = padded pixels / (976*1728).
@@ -326,13 +328,21 @@ def main():
         evals = 14 if args.solver_mode == "fast" else args.denoise_steps
         a = prof_u["attn_self"]
         l0_flops = a["max_flops"]                       # the largest launches = the L0 layers (N = H*W of the padded latent)
-        traffic = None
-        tname = next((n for n in ("r04_attn_v5_traffic.json", "r03_attn_v5_traffic.json") if os.path.isfile(os.path.join(ROOT, "profiles", n))),
-                     "r04_attn_v5_traffic.json")    # the newest PMC collection of the (unchanged) kernel at this shape
-        tpath = os.path.join(ROOT, "profiles", tname)
-        if os.path.isfile(tpath) and not args.small and args.config in ("cfg2", "cfg3") and not custom:   # PMC pass of the same kernel at the same shape
-            traffic = json.load(open(tpath))["traffic_bytes_per_launch"]
-        roof = {"bound": "mfma", "kernel": "flash_attn_v5_kernel (spatial self-attention, d=64)", "unit": "TFLOP/s",
+        # HBM-side traffic of the dominant kernel: the NEWEST committed PMC collection (profiles/rNN_attn*_traffic.json, highest round
+        # first) whose `kernel` names the kernel this run launched; a file of another kernel is not quoted (traffic = null)
+        import glob as _glob
+        traffic, tname = None, None
+        for tp in sorted(_glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_attn*_traffic.json")), reverse=True):
+            try:
+                tj = json.load(open(tp))
+            except Exception:
+                continue
+            if ROOFLINE_KERNEL in tj.get("kernel", "") and "traffic_bytes_per_launch" in tj:
+                tname = os.path.basename(tp)
+                if not args.small and args.config in ("cfg2", "cfg3") and not custom:   # PMC pass of the same kernel at the same shape
+                    traffic = tj["traffic_bytes_per_launch"]
+                break
+        roof = {"bound": "mfma", "kernel": f"{ROOFLINE_KERNEL} (spatial self-attention, d=64)", "unit": "TFLOP/s",
                 "achieved": (l0_flops / (a["max_flops_ms"] * 1e-3) / 1e12) if a["max_flops_ms"] else None,
                 "peak": PEAK_BF16_MFMA / 1e12, "traffic": traffic,
                 "traffic_source": f"profiles/{tname} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch)" if traffic else None,
@@ -371,6 +381,26 @@ def main():
         breakdown = None if prof_u_all is None else {k: {"ms": round(v["ms"], 1), "launches": v["launches"],
                          "TFLOP/s": round(v["flops"] / v["ms"] / 1e9, 1) if v["ms"] and v["flops"] else None,
                          "GB/s": round(v["bytes"] / v["ms"] / 1e6, 1) if v["ms"] else None} for k, v in prof_u_all.items()}
+        # every kernel family of the UNet against the roof that bounds it (the per-family table of the untimed breakdown step): MFMA
+        # families in TFLOP/s of their algorithmic FLOPs against the nominal dense peak, HBM families in GB/s of their algorithmic bytes
+        # against 8 TB/s.  `share` = the family's part of the summed kernel time of that step.
+        if prof_u_all is not None:
+            fam_bound = {"attn_self": "mfma", "gemm": "mfma", "conv3x3": "mfma", "tconv": "mfma", "attn_cross": "hbm", "temporal_attn": "hbm",
+                         "group_norm": "hbm", "layer_norm": "hbm", "misc": "hbm"}
+            tot_ms = sum(v["ms"] for v in prof_u_all.values()) or 1.0
+            fams = {}
+            for k, v in prof_u_all.items():
+                if not v["ms"]:
+                    continue
+                if fam_bound.get(k) == "mfma":
+                    ach, pk, unit = v["flops"] / v["ms"] / 1e9, PEAK_BF16_MFMA / 1e12, "TFLOP/s"
+                else:
+                    ach, pk, unit = v["bytes"] / v["ms"] / 1e6, PEAK_HBM / 1e9, "GB/s"
+                fams[k] = {"bound": fam_bound.get(k, "hbm"), "achieved": round(ach, 1), "peak": pk, "unit": unit, "frac": round(ach / pk, 4),
+                           "ms": round(v["ms"], 1), "share": round(v["ms"] / tot_ms, 4), "launches": v["launches"]}
+            roof["families"] = fams
+            roof["families_note"] = ("one UNTIMED clip with HIP events around every launch; achieved = the family's algorithmic FLOPs (or bytes: every "
+                                     "operand read once, the output written once) / its summed launch time; weakest MFMA family first to fix")
         line = {
             "metric": "upscaled frames/sec (4x, 32f 240x426 chunk)" if args.config == "cfg2" and not custom else
                       f"upscaled frames/sec (4x, {args.frames}f {args.height}x{args.width}; BASELINE {args.config}{' modified' if custom else ''})",

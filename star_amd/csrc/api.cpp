@@ -31,6 +31,10 @@ void rt_note_launch_error(const char* what) {
   g_launch_err += rt::last_error_string();   // also clears HIP's sticky "last error"
 }
 }
+// every entry point that takes a context: a null context is error 1 (there is nowhere to put a message); otherwise follow the
+// CONTEXT's device, not the caller's current one
+#define STAR_ENTER(h) do { if (!(h)) return 1; rt::set_device((h)->c.device); } while (0)
+
 static int finish(star_ctx* h, int rc) {
   if (rc) { g_launch_err.clear(); return rc; }
   if (!g_launch_err.empty()) {
@@ -103,7 +107,7 @@ int star_set_stream(star_ctx* h, void* s) {
   return 0;
 }
 int star_sync(star_ctx* h) {
-  if (h) rt::set_device(h->c.device);   // follow the context's device, not the caller's current one
+  STAR_ENTER(h);
   if (rt::stream_sync(h->c.stream)) return h->c.fail(std::string("sync failed: ") + rt::last_error_string());
   return 0;
 }
@@ -122,7 +126,7 @@ int64_t star_ln_fused_count(star_ctx* h) { return h ? (int64_t)h->c.ln_fused : 0
 
 static int gemm_from_desc(star_ctx* h, const star_gemm_desc* d, float* gn_partial, bool* gn_done, float* ln_partial = nullptr, int ln_cap = 0,
                           int* ln_parts = nullptr, bool* ln_done = nullptr) {
-  if (h) rt::set_device(h->c.device);   // follow the context's device, not the caller's current one
+  STAR_ENTER(h);
   GemmArgs a;
   a.gn_partial = gn_partial; a.gn_done = gn_done;
   a.ln_partial = ln_partial; a.ln_parts_cap = ln_cap; a.ln_parts = ln_parts; a.ln_done = ln_done;
@@ -139,6 +143,7 @@ int star_gemm(star_ctx* h, const star_gemm_desc* d) { return gemm_from_desc(h, d
 int star_gemm_gn(star_ctx* h, const star_gemm_desc* d, float* gn_partial, int32_t* wrote) {
   bool done = false;
   if (wrote) *wrote = 0;
+  if (!h) return 1;
   if (!gn_partial) return finish(h, h->c.fail("gemm_gn: null partial buffer"));
   const int rc = gemm_from_desc(h, d, gn_partial, &done);
   if (wrote) *wrote = done ? 1 : 0;
@@ -147,7 +152,7 @@ int star_gemm_gn(star_ctx* h, const star_gemm_desc* d, float* gn_partial, int32_
 
 
 int star_attn_fwd(star_ctx* h, const star_attn_desc* d) {
-  if (h) rt::set_device(h->c.device);   // follow the context's device, not the caller's current one
+  STAR_ENTER(h);
   AttnArgs a;
   a.Q = d->Q; a.K = d->K; a.V = d->V; a.O = d->O;
   a.ldq = d->ldq; a.ldk = d->ldk; a.ldv = d->ldv; a.ldo = d->ldo;
@@ -156,7 +161,7 @@ int star_attn_fwd(star_ctx* h, const star_attn_desc* d) {
   return finish(h, op_flash_attn(&h->c, a));
 }
 int star_temporal_attn_fwd(star_ctx* h, const star_tattn_desc* d) {
-  if (h) rt::set_device(h->c.device);   // follow the context's device, not the caller's current one
+  STAR_ENTER(h);
   TAttnArgs a;
   a.Q = d->Q; a.K = d->K; a.V = d->V; a.O = d->O;
   a.ldq = d->ldq; a.ldk = d->ldk; a.ldv = d->ldv; a.ldo = d->ldo;
@@ -164,8 +169,8 @@ int star_temporal_attn_fwd(star_ctx* h, const star_tattn_desc* d) {
   return finish(h, op_temporal_attn(&h->c, a));
 }
 int star_temporal_qkv_attn(star_ctx* h, const star_tq_desc* d) {
-  if (h) rt::set_device(h->c.device);
-  if (!h || !d) return 1;
+  STAR_ENTER(h);
+  if (!d) return 1;
   TqArgs a;
   a.A = d->A; a.W = d->W; a.O = d->O; a.bias = d->bias; a.colsum = d->colsum; a.rowab = d->rowab;
   a.lda = d->lda; a.ldo = d->ldo; a.HW = d->HW; a.F = d->F; a.C = d->C; a.heads = d->heads; a.scale = d->scale;
@@ -176,6 +181,7 @@ int star_gemm_rowstats(star_ctx* h, const star_gemm_desc* d, float* ln_partial, 
   int np = 0;
   if (wrote) *wrote = 0;
   if (parts) *parts = 0;
+  if (!h) return 1;
   if (!ln_partial || parts_cap <= 0) return finish(h, h->c.fail("gemm_rowstats: null partial buffer"));
   const int rc = gemm_from_desc(h, d, nullptr, nullptr, ln_partial, parts_cap, &np, &done);
   if (wrote) *wrote = done ? 1 : 0;
@@ -184,57 +190,56 @@ int star_gemm_rowstats(star_ctx* h, const star_gemm_desc* d, float* ln_partial, 
 }
 int star_layer_norm_rowab_from_partials(star_ctx* h, const float* ln_partial, int32_t parts, float* rowab, int32_t rows, int32_t C, float eps,
                                         int32_t mode, const float* gate_w, float* maps, int32_t H, int32_t W) {
-  if (h) rt::set_device(h->c.device);
-  if (!h) return 1;
+  STAR_ENTER(h);
   return finish(h, op_layer_norm_from_partials(&h->c, ln_partial, parts, rows, C, eps, mode, gate_w, maps, H, W, rowab));
 }
 int star_group_norm_from_partials(star_ctx* h, const void* x, int32_t ldx, void* y, int32_t ldy, const float* gamma, const float* beta,
                                   int32_t rows, int32_t C, int32_t rows_per_stat, float eps, int32_t silu, const float* gn_partial) {
-  if (h) rt::set_device(h->c.device);
+  STAR_ENTER(h);
   if (!y) return finish(h, h->c.fail("group_norm_from_partials: null output"));
+  if (!gn_partial) return finish(h, h->c.fail("group_norm_from_partials: null partial buffer (star_gemm_gn writes it)"));
   return finish(h, op_group_norm_fused(&h->c, x, ldx, y, ldy, gamma, beta, rows, C, rows_per_stat, eps, silu != 0, gn_partial));
 }
 int star_group_norm(star_ctx* h, const void* x, int32_t ldx, void* y, int32_t ldy, const float* gamma,
                     const float* beta, int32_t rows, int32_t C, int32_t rows_per_stat, float eps, int32_t silu) {
-  if (h) rt::set_device(h->c.device);   // follow the context's device, not the caller's current one
+  STAR_ENTER(h);
   return finish(h, op_group_norm(&h->c, x, ldx, y, ldy, gamma, beta, rows, C, rows_per_stat, eps, silu != 0));
 }
 int star_layer_norm(star_ctx* h, const void* x, int32_t ldx, void* y, int32_t ldy, const float* gamma,
                     const float* beta, int32_t rows, int32_t C, float eps, int32_t mode, const float* gate_w,
                     float* maps, int32_t H, int32_t W) {
-  if (h) rt::set_device(h->c.device);   // follow the context's device, not the caller's current one
+  STAR_ENTER(h);
   return finish(h, op_layer_norm(&h->c, x, ldx, y, ldy, gamma, beta, rows, C, eps, mode, gate_w, maps, H, W));
 }
 int star_layer_norm_rowab(star_ctx* h, const void* x, int32_t ldx, float* rowab, int32_t rows, int32_t C, float eps, int32_t mode,
                           const float* gate_w, float* maps, int32_t H, int32_t W) {
-  if (h) rt::set_device(h->c.device);
-  if (!h) return 1;
+  STAR_ENTER(h);
   if (!rowab) return finish(h, h->c.fail("layer_norm_rowab: null output"));
   if (mode == LN_STATS_ONLY) return finish(h, h->c.fail("layer_norm_rowab: mode 3 (maps only) has no row statistics; use star_layer_norm"));
   return finish(h, op_layer_norm(&h->c, x, ldx, nullptr, 8, nullptr, nullptr, rows, C, eps, mode, gate_w, maps, H, W, rowab));
 }
 int star_concat_add(star_ctx* h, const void* a, const void* b, const void* c, void* out, int32_t rows, int32_t C1, int32_t C2) {
-  if (h) rt::set_device(h->c.device);   // follow the context's device, not the caller's current one
+  STAR_ENTER(h);
   return finish(h, op_concat_add(&h->c, a, b, c, out, rows, C1, C2));
 }
 int star_add(star_ctx* h, const void* a, const void* b, void* out, int64_t n) {
-  if (h) rt::set_device(h->c.device);
+  STAR_ENTER(h);
   return finish(h, op_add(&h->c, a, b, out, n));
 }
 int star_stem_im2col(star_ctx* h, const float* latent, void* out, int32_t Cl, int32_t F, int32_t H, int32_t W) {
-  if (h) rt::set_device(h->c.device);   // follow the context's device, not the caller's current one
+  STAR_ENTER(h);
   return finish(h, op_stem_im2col(&h->c, latent, out, Cl, F, H, W));
 }
 int star_rows_to_latent(star_ctx* h, const float* rows, float* out, int32_t Cl, int32_t ld, int64_t ntok) {
-  if (h) rt::set_device(h->c.device);   // follow the context's device, not the caller's current one
+  STAR_ENTER(h);
   return finish(h, op_rows_to_latent(&h->c, rows, out, Cl, ld, ntok));
 }
 int star_gemv(star_ctx* h, const float* x, const void* W, const float* b, float* y, int32_t N, int32_t K, int32_t silu_in, int32_t silu_out) {
-  if (h) rt::set_device(h->c.device);   // follow the context's device, not the caller's current one
+  STAR_ENTER(h);
   return finish(h, op_gemv(&h->c, x, W, b, y, N, K, silu_in != 0, silu_out != 0));
 }
 int star_cast(star_ctx* h, const float* x, void* y, int64_t n) {
-  if (h) rt::set_device(h->c.device);
+  STAR_ENTER(h);
   return finish(h, op_cast(&h->c, x, y, n));
 }
 
@@ -253,7 +258,7 @@ int star_load_tensor(star_ctx* h, const char* name, const void* host, const int6
 }
 int star_clear_staged(star_ctx* h) { h->c.host_tensors.clear(); return 0; }
 int star_unet_build(star_ctx* h, const star_unet_config* c) {
-  if (h) rt::set_device(h->c.device);   // follow the context's device, not the caller's current one
+  STAR_ENTER(h);
   UNetCfg cfg;
   cfg.in_dim = c->in_dim; cfg.dim = c->dim; cfg.context_dim = c->context_dim; cfg.out_dim = c->out_dim;
   cfg.n_levels = c->n_levels;
@@ -265,12 +270,12 @@ int star_unet_build(star_ctx* h, const star_unet_config* c) {
   return finish(h, unet_build(&h->c, cfg));
 }
 int star_unet_forward(star_ctx* h, const float* xt, int64_t t, const float* y, const float* hint, float* out, int32_t f, int32_t hh, int32_t w) {
-  if (h) rt::set_device(h->c.device);   // follow the context's device, not the caller's current one
+  STAR_ENTER(h);
   return finish(h, unet_forward(&h->c, xt, (long long)t, y, hint, out, f, hh, w));
 }
 int star_unet_forward_cfg(star_ctx* h, const float* xt, int64_t t, const float* y_cond, const float* y_uncond, const float* hint,
                           float* out_cond, float* out_uncond, int32_t f, int32_t hh, int32_t w) {
-  if (h) rt::set_device(h->c.device);
+  STAR_ENTER(h);
   const float* ys[2] = {y_cond, y_uncond};
   float* outs[2] = {out_cond, out_uncond};
   return finish(h, unet_forward_n(&h->c, xt, (long long)t, ys, hint, outs, 2, f, hh, w));
@@ -282,18 +287,18 @@ int star_unet_graph(star_ctx* h, int32_t enable) {
 }
 int star_controlnet_forward(star_ctx* h, const float* xt, int64_t t, const float* y, const float* hint, void* const* residuals,
                             int32_t n_residuals, int32_t f, int32_t hh, int32_t w) {
-  if (h) rt::set_device(h->c.device);
+  STAR_ENTER(h);
   return finish(h, controlnet_forward(&h->c, xt, (long long)t, y, hint, residuals, n_residuals, f, hh, w));
 }
 int star_module_run(star_ctx* h, int32_t kind, const char* prefix, int32_t cin, int32_t cout, int32_t heads, int32_t embed_dim,
                     int32_t context_dim, const void* x, const float* emb, const float* context, void* out, int32_t f, int32_t hh, int32_t w) {
-  if (h) rt::set_device(h->c.device);   // follow the context's device, not the caller's current one
+  STAR_ENTER(h);
   return finish(h, module_run(&h->c, kind, prefix, cin, cout, heads, embed_dim, context_dim, x, emb, context, out, f, hh, w));
 }
 
 
 int star_vae_build(star_ctx* h, const star_vae_config* c) {
-  if (h) rt::set_device(h->c.device);   // follow the context's device, not the caller's current one
+  STAR_ENTER(h);
   VaeCfg cfg;
   cfg.in_ch = c->in_ch; cfg.out_ch = c->out_ch; cfg.latent = c->latent; cfg.n_blocks = c->n_blocks;
   for (int i = 0; i < 8; ++i) cfg.block_out[i] = c->block_out[i];
@@ -303,11 +308,11 @@ int star_vae_build(star_ctx* h, const star_vae_config* c) {
   return finish(h, vae_build(&h->c, cfg));
 }
 int star_vae_encode(star_ctx* h, const float* x, float* moments, int32_t n, int32_t H, int32_t W) {
-  if (h) rt::set_device(h->c.device);
+  STAR_ENTER(h);
   return finish(h, vae_encode(&h->c, x, moments, n, H, W));
 }
 int star_vae_decode(star_ctx* h, const float* z, float* out, int32_t n, int32_t hh, int32_t w) {
-  if (h) rt::set_device(h->c.device);
+  STAR_ENTER(h);
   return finish(h, vae_decode(&h->c, z, out, n, hh, w));
 }
 int star_dit_build(star_ctx* h, const star_dit_config* c) {
@@ -322,7 +327,7 @@ int star_dit_block_forward(star_ctx* h, int32_t layer, const void* hidden_in, co
   return finish(h, dit_block_forward(&h->c, layer, hidden_in, emb, hidden_out, text_len, T, H, W));
 }
 int star_softmax_rows(star_ctx* h, const float* s, int32_t lds, void* p, int32_t ldp, int32_t rows, int32_t n, float scale) {
-  if (h) rt::set_device(h->c.device);   // follow the context's device, not the caller's current one
+  STAR_ENTER(h);
   return finish(h, op_softmax_rows(&h->c, s, lds, p, ldp, rows, n, scale));
 }
 
@@ -372,7 +377,7 @@ int star_profile_begin_kinds(star_ctx* h, uint32_t kind_mask) {
   return rc;
 }
 int star_profile_end(star_ctx* h, star_prof_entry* out) {
-  if (h) rt::set_device(h->c.device);   // follow the context's device, not the caller's current one
+  STAR_ENTER(h);
   rt::stream_sync(h->c.stream);
   if (const char* path = getenv("STAR_PROF_DETAIL")) {   // per-launch records: kind, dims, ms
     if (FILE* f = fopen(path, "a")) {

@@ -54,6 +54,15 @@ static int launch_flash(Ctx* ctx, const AttnArgs& a) {
     if constexpr (__is_same(T, f16)) { STAR_LAUNCH((flash_attn_v5_kernel<T, 1, 0>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p); return 0; }
     else { STAR_LAUNCH((flash_attn_v5_kernel<T, 0, 0>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p); return 0; }
   }
+  if (a.variant == 34) {   // round 6: ONE 512-thread workgroup per CU, eight waves share a K / V stage (attn5.h NW = 8); bit-identical to the product kernel
+    p.nqb = (a.Nq + 511) / 512;
+    const long long nblk8 = 8LL * p.nqb * ((BH + 7) / 8);
+    if constexpr (__is_same(T, f16)) {
+      if (a.Nk >= 1024) { STAR_LAUNCH((flash_attn_v5_kernel<T, 1, 1, 0, 8>), dim3((unsigned)nblk8), dim3(512), (size_t)32768, ctx->stream, p); return 0; }
+    }
+    STAR_LAUNCH((flash_attn_v5_kernel<T, 0, 1, 0, 8>), dim3((unsigned)nblk8), dim3(512), (size_t)32768, ctx->stream, p);
+    return 0;
+  }
   if (a.variant == 32) { STAR_LAUNCH((flash_attn_v3_kernel<T, 2, 1, 0, 1>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p); return 0; }   // the product kernel of rounds 1-2
   if (a.variant == 30) { STAR_LAUNCH((flash_attn_v5_kernel<T, 0>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p); return 0; }
   if (a.variant == 31) {

@@ -24,10 +24,15 @@ namespace star {
 
 // CAUSAL = 1 (text tower, embedder.py:59: open_clip's attn_mask): key j is visible to query i only for j <= i; Nq == Nk, the mask
 // is applied to the scores of every tile (and again on the recompute path), so masked probabilities are exact zeros.
-template <class T, int PKSUM, int AUGK8 = 0, int CAUSAL = 0>   // AUGK8: the augmented k-step as a half-depth 32x32x8 MFMA (one useful k of 8 instead of 16: +1-4 %, bit-identical; shipped)
-STAR_GLOBAL void STAR_LAUNCH_BOUNDS(256, 2)
+// NW: waves per workgroup.  4 = the shipped form (two workgroups per CU, each staging its own K / V tiles); 8 = ONE 512-thread workgroup
+// per CU whose eight waves share one K / V stage (round 6, VERDICT r05 item 5: half the L2 -> LDS bytes per flop; the waves run free
+// between the per-tile barriers).  Same arithmetic per query row: bit-identical outputs.
+template <class T, int PKSUM, int AUGK8 = 0, int CAUSAL = 0, int NW = 4>   // AUGK8: the augmented k-step as a half-depth 32x32x8 MFMA (one useful k of 8 instead of 16: +1-4 %, bit-identical; shipped)
+STAR_GLOBAL void STAR_LAUNCH_BOUNDS(NW * 64, 8 / NW)
 flash_attn_v5_kernel(const AttnParams p) {
-  constexpr int NQ = 2, QW = 64, QB = 256, KT = 64, TILE = KT * 128, BUFB = 2 * TILE;   // one buffer = K tile | V tile (16 KB)
+  constexpr int NQ = 2, QW = 64, QB = NW * 64, KT = 64, TILE = KT * 128, BUFB = 2 * TILE;   // one buffer = K tile | V tile (16 KB)
+  constexpr int NT = NW * 64, NJ = 512 / NT;     // threads; 16-byte chunks per thread and operand tile (64 rows x 8 chunks)
+  static_assert(NW == 4 || NW == 8, "");
   constexpr float LAZY_BIG = 1024.0f;
   static_assert(PKSUM == 0 || sizeof(T) == 2, "");
   char* smem = dyn_smem();
@@ -70,10 +75,10 @@ flash_attn_v5_kernel(const AttnParams p) {
 
   // ---- K/V staging: thread (j, tid) copies 16-B chunk (tid & 7) ^ swizzle of tile row r_j = (j*256 + tid) >> 3
   const int pos = tid & 7;
-  uint32_t koff[2], voff[2];       // loop-invariant byte offsets of this lane's two chunks from the tile's first row
+  uint32_t koff[NJ], voff[NJ];     // loop-invariant byte offsets of this lane's chunks from the tile's first row
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int r = (j * 256 + tid) >> 3;
+  for (int j = 0; j < NJ; ++j) {
+    const int r = (j * NT + tid) >> 3;
     const int c = pos ^ ((r >> 1) & 7);
     koff[j] = (uint32_t)(r * p.ldk + c * 8) * 2u;
     voff[j] = (uint32_t)(r * p.ldv + c * 8) * 2u;
@@ -89,19 +94,19 @@ flash_attn_v5_kernel(const AttnParams p) {
       const char* kt = (const char*)Kg + (size_t)t * kstep;   // wave-uniform
       const char* vt = (const char*)Vg + (size_t)t * vstep;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        glds16_su(kt, koff[j], kdst + (size_t)(j * 256 + wv * 64) * 16);
-        glds16_su(vt, voff[j], vdst + (size_t)(j * 256 + wv * 64) * 16);
+      for (int j = 0; j < NJ; ++j) {
+        glds16_su(kt, koff[j], kdst + (size_t)(j * NT + wv * 64) * 16);
+        glds16_su(vt, voff[j], vdst + (size_t)(j * NT + wv * 64) * 16);
       }
     } else {                       // the ragged last tile: rows past Nk re-read the last key (masked in the scores)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int r = (j * 256 + tid) >> 3;
+      for (int j = 0; j < NJ; ++j) {
+        const int r = (j * NT + tid) >> 3;
         const int c = pos ^ ((r >> 1) & 7);
         int key = t * KT + r;
         if (key > p.Nk - 1) key = p.Nk - 1;
-        glds16(Kg + (size_t)key * p.ldk + c * 8, kdst + (size_t)(j * 256 + wv * 64) * 16);
-        glds16(Vg + (size_t)key * p.ldv + c * 8, vdst + (size_t)(j * 256 + wv * 64) * 16);
+        glds16(Kg + (size_t)key * p.ldk + c * 8, kdst + (size_t)(j * NT + wv * 64) * 16);
+        glds16(Vg + (size_t)key * p.ldv + c * 8, vdst + (size_t)(j * NT + wv * 64) * 16);
       }
     }
   };

@@ -21,6 +21,10 @@ static int launch_astat(Ctx* ctx, const GemmArgs& a) {
   p.rowab = a.rowab; p.colsum = a.colsum;
   const size_t smem = 2 * (size_t)40960 + 4 * (size_t)8192 + 2 * (size_t)a.N * sizeof(float);   // W ring, per-wave staging blocks, bias + colsum
   const dim3 grid((unsigned)((a.M + 255) / 256)), block(256);
+  {   // staggered first round (gemm_as.h): one workgroup per CU is resident, so the first round is the first num_cus workgroups
+    const int cus = a.assume_cus > 0 ? a.assume_cus : (ctx->num_cus > 0 ? ctx->num_cus : 256);
+    p.tiles_m = (long long)grid.x >= 4LL * cus ? cus : 0;
+  }
 #ifdef STAR_BENCH_VARIANTS   // timing ablations (wrong results): no epilogue / no W staging / W fragments not re-read
   if (a.force_tile == 31) { STAR_LAUNCH((gemm_astat_kernel<T, 0, 1>), grid, block, smem, ctx->stream, p); return 0; }
   if (a.force_tile == 32) { STAR_LAUNCH((gemm_astat_kernel<T, 0, 2>), grid, block, smem, ctx->stream, p); return 0; }

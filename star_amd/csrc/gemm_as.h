@@ -49,7 +49,9 @@ gemm_astat_kernel(const GemmParams p) {
   constexpr bool DRAIN_ALL = ABL_ == 10;
   constexpr bool STAGGER = ABL_ != 12;
   if constexpr (STAGGER) {
-    if (blockIdx.x < 256 && gridDim.x >= 1024) wave_sleep(((int)(blockIdx.x >> 3) & 7) * (ABL_ == 11 ? p.group_m : 1) * 127);
+    // p.tiles_m (unused by this kernel otherwise) = the stagger window, set by the launcher from the device's CU count: the workgroups of the
+    // FIRST round (one per CU), and only on launches of >= 4 rounds; 0 = no stagger (the window was a literal 256)
+    if ((int)blockIdx.x < p.tiles_m) wave_sleep(((int)(blockIdx.x >> 3) & 7) * (ABL_ == 11 ? p.group_m : 1) * 127);
   }
   char* smem = dyn_smem();
   char* stg = smem + 2 * WTILE + wave_uniform((int)threadIdx.x >> 6) * STG;

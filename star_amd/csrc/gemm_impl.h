@@ -219,6 +219,20 @@ static int launch_gemm(Ctx* ctx, const GemmArgs& a) {
       if (a.epi & (EPI_OUT_F32 | EPI_ROWAFF | EPI_GELU_TANH | EPI_GEGLU)) return ctx->fail("gemm: tile 17 has the plain and residual 16-bit epilogues only");
       return launch_gemm_f<T, 256, 256, 2, 2, 1, false, false, 0, false, 1, 0, true>(ctx, a);
     case 18: return launch_gemm_persist(ctx, a);   // persistent one-wave-per-SIMD tile with a wave-private epilogue (gemm_p.h)
+#ifdef STAR_BENCH_VARIANTS   // round-6 A/Bs of tile 18's walk and store policy (bit-identical): 60 = non-temporal stores (+ 66: on column strips of 8);
+    // 61 / 62 / 63 = row groups of 1 / 4 / 16 (product: 8 where a tile row is >= 12 tiles wide); 64 / 65 / 67 = column strips of 8 / 4 / 16
+    case 60: return launch_gemm_persist(ctx, a);
+    // 69 = tile 9 (two independent 4-wave workgroups per CU on 128 x 256 tiles: one group's GEGLU epilogue runs beside the other's K loop)
+    // WITH the folded-LayerNorm flavour, so that it can run the model's GEGLU layers
+    case 69: return launch_gemm_t<T, 128, 256, 2, 2, 2, false, 3, true>(ctx, a);
+    case 61: case 62: case 63: case 64: case 65: case 66: case 67: {
+      GemmArgs b = a;
+      static const int gm[7] = {1, 4, 16, -8, -4, -8, -16};
+      b.group_m = gm[tile - 61];
+      b.force_tile = tile == 66 ? 60 : 18;
+      return launch_gemm_persist(ctx, b);
+    }
+#endif
     case 3: return launch_gemm_t<T, 128, 128, 2, 2, 2, false, 0, true, true>(ctx, a);
     case 4: return launch_gemm_t<T, 256, 128, 4, 1, 1, false, 0, true>(ctx, a);
 #ifdef STAR_BENCH_VARIANTS   // A/B experiments of round 1 / 2 that lost to the tiles above (profiles/r01_gemm_ablation.txt, r02_gemm8_ablation.txt)

@@ -23,7 +23,7 @@ static int launch_persist_t(Ctx* ctx, const GemmArgs& a) {
   p.m_off = a.m_off;
   p.tiles_m = ((a.m_end > 0 ? a.m_end : a.M) - a.m_off + 255) / 256;
   p.tiles_n = (a.N + 255) / 256;
-  p.group_m = a.group_m >= 0 ? a.group_m : (p.tiles_n >= 12 ? 8 : 1);
+  p.group_m = a.group_m != -1 ? a.group_m : (p.tiles_n >= 12 ? 8 : 1);   // (< -1: column strips, bench A/B)
   const int nblk = p.tiles_m * p.tiles_n;
   if (nblk <= 0) return 0;
   const int cus = a.assume_cus > 0 ? a.assume_cus : (ctx->num_cus > 0 ? ctx->num_cus : 256);
@@ -31,6 +31,16 @@ static int launch_persist_t(Ctx* ctx, const GemmArgs& a) {
   if (G >= 8) G &= ~7;
   constexpr size_t smem = 2 * (size_t)(256 + 256) * 128 + 4 * (size_t)4096 + 2 * (size_t)2048;
   const dim3 grid((unsigned)G), block(256);
+#ifdef STAR_BENCH_VARIANTS   // round-6 A/B (correct results, bit-identical): 60 = non-temporal output stores
+  if (a.force_tile == 60) {
+    if ((a.epi & EPI_ROWAFF) && (a.epi & EPI_GEGLU)) STAR_LAUNCH((gemm_persist_kernel<T, 10, 2>), grid, block, smem, ctx->stream, p);
+    else if (a.epi & EPI_GEGLU) STAR_LAUNCH((gemm_persist_kernel<T, 2, 2>), grid, block, smem, ctx->stream, p);
+    else if (a.epi & EPI_ROWAFF) STAR_LAUNCH((gemm_persist_kernel<T, 8, 2>), grid, block, smem, ctx->stream, p);
+    else if (a.epi & EPI_RES) STAR_LAUNCH((gemm_persist_kernel<T, 1, 2>), grid, block, smem, ctx->stream, p);
+    else STAR_LAUNCH((gemm_persist_kernel<T, 0, 2>), grid, block, smem, ctx->stream, p);
+    return 0;
+  }
+#endif
   if ((a.epi & EPI_ROWAFF) && (a.epi & EPI_GEGLU)) STAR_LAUNCH((gemm_persist_kernel<T, 10>), grid, block, smem, ctx->stream, p);
   else if (a.epi & EPI_GEGLU) STAR_LAUNCH((gemm_persist_kernel<T, 2>), grid, block, smem, ctx->stream, p);
   else if (a.epi & EPI_ROWAFF) STAR_LAUNCH((gemm_persist_kernel<T, 8>), grid, block, smem, ctx->stream, p);

@@ -25,7 +25,8 @@
 
 namespace star {
 
-template <class T, int EPIF>   // EPIF: bit 0 residual add, bit 1 GEGLU (weight rows in 32-row (value, gate) blocks), bit 3 row-affine (folded LayerNorm); 16-bit output
+// STPOL: cache policy of the output stores (prim.h: buf_store16_pol; 0 = plain, 2 = non-temporal) -- round-6 A/B, bench build only
+template <class T, int EPIF, int STPOL = 0>   // EPIF: bit 0 residual add, bit 1 GEGLU (weight rows in 32-row (value, gate) blocks), bit 3 row-affine (folded LayerNorm); 16-bit output
 STAR_GLOBAL void STAR_LAUNCH_BOUNDS(256, 1)
 gemm_persist_kernel(const GemmParams p) {
   constexpr int BM = 256, BN = 256, NT = 256, NP = 8;      // NP: 16-byte pieces per thread and operand and K tile
@@ -55,6 +56,15 @@ gemm_persist_kernel(const GemmParams p) {
       bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
     }
     int tile_m = bid / p.tiles_n, tile_n = bid % p.tiles_n;
+    if (p.group_m < -1) {
+      // round-6 A/B: ROW-major inside strips of -group_m tile COLUMNS: the 32 tiles an XCD runs together are (32 / strip) rows x strip
+      // columns, and the following tiles keep the strip's W panels (hot in the L2) while the A panels stream past once per strip
+      const int gn = -p.group_m, per_group = gn * p.tiles_m;
+      const int g = bid / per_group, in = bid - g * per_group;
+      const int cols = p.tiles_n - g * gn < gn ? p.tiles_n - g * gn : gn;
+      tile_n = g * gn + in % cols;
+      tile_m = in / cols;
+    } else
     if (p.group_m > 1) {
       const int per_group = p.group_m * p.tiles_n;
       const int g = bid / per_group, in = bid - g * per_group;
@@ -314,7 +324,7 @@ gemm_persist_kernel(const GemmParams p) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) ov[e] = from_f32<T>(to_f32<T>(ov[e]) + to_f32<T>(rv[u][e]));
         }
-        buf_store16(crs, (voff + (uint32_t)(GEGLUF ? 0 : jh * 128)) | ((!GEGLUF && jh) ? dead1 : dead0), __builtin_bit_cast(u32x4, ov));
+        buf_store16_pol<STPOL>(crs, (voff + (uint32_t)(GEGLUF ? 0 : jh * 128)) | ((!GEGLUF && jh) ? dead1 : dead0), __builtin_bit_cast(u32x4, ov));
         voff += step;                                   // next 8 rows
       }
       if constexpr (!GEGLUF && jh == 0) voff -= 4 * step;   // back to the unit's first rows for the second half

@@ -281,7 +281,11 @@ struct Runner {
       part = std::make_shared<Buf>(ctx, (size_t)((g.M + 31) / 32) * g.N * sizeof(float));
       if (part->p) { g.gn_partial = part->as<float>(); g.gn_done = &done; }
     } else if (rowstats && y && ln_epi_enabled() && g.mode == A_PLAIN && g.N <= 640 && !(g.N & 7)) {
-      const int cap = 2 * ((g.N + 127) / 128);
+      // two parts per column tile of the tile the launcher will choose (gemm_impl.h: 128 x 128 for small problems, else 256 x 320 for the
+      // 320-multiple widths; any other choice drops the request, and the launcher re-checks the capacity): at level 0 that is 2 parts per
+      // row (32 bytes), not the 128-column worst case's 6 (81 MB allocated per producer for 27 MB used)
+      const bool small_tile = g.M <= 4096 && g.N <= 1024;
+      const int cap = (!small_tile && g.N % 320 == 0) ? 2 * (g.N / 320) : 2 * ((g.N + 127) / 128);
       lpart = std::make_shared<Buf>(ctx, (size_t)g.M * cap * 4 * sizeof(float));
       if (lpart->p) { g.ln_partial = lpart->as<float>(); g.ln_parts_cap = cap; g.ln_parts = &lparts; g.ln_done = &ldone; }
     }

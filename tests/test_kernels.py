@@ -439,7 +439,7 @@ def ref_attention(q, k, v, heads):
     return o.transpose(1, 2).reshape(B, -1, heads * 64)
 
 
-@pytest.mark.parametrize("variant", [9, 40, 41])
+@pytest.mark.parametrize("variant", [9, 34, 40, 41])
 @pytest.mark.parametrize("B,heads,Nq,Nk", [(2, 2, 300, 300), (1, 5, 80, 80), (3, 1, 257, 64), (1, 2, 64, 1), (9, 1, 33, 130), (1, 1, 130, 129)])
 def test_flash_attention_self(ctx, dtype, B, heads, Nq, Nk, variant):
     """spatial self-attention (unet_v2v.py:472 -> :184) on a fused QKV buffer, ragged q/k tails."""
@@ -769,6 +769,58 @@ def test_group_norm_statistics_in_the_producer_epilogue(ctx, dtype, mode, tile, 
     # a tile without the flavour: the output is still computed, no partials
     out4, part4 = ctx.gemm(a, w, bias=b, res=res, force_tile=4 if mode == "plain" else 1, gn_partial=True, **kw)
     assert part4 is None and out4.shape == out.shape
+
+
+def test_group_norm_statistics_across_a_tail_split(ctx, dtype):
+    """with the automatic tile choice a poorly filled last round goes to a second launch of 128 x 128 tiles (gemm_impl.h, tail
+    split); BOTH launches write the same partial buffer.  4500 rows x 320 columns on 17 assumed CUs: 18 tiles of 256 x 320 = 17 in the
+    main launch (4352 rows = 136 whole slots) + 148 rows in the remainder.  The output is bit-identical to the forced single launch and
+    the partials are the pair sums of all 4500 stored rows."""
+    g = torch.Generator().manual_seed(4500)
+    M, K, N = 4500, 64, 320
+    a = dev(ctx, torch.randn(M, K, generator=g).to(dtype))
+    w = dev(ctx, (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dtype))
+    b = dev(ctx, torch.randn(N, generator=g))
+    res = dev(ctx, (torch.randn(M, N, generator=g) * 0.7 + 0.3).to(dtype))
+    plain = ctx.gemm(a, w, bias=b, res=res, force_tile=2)
+    n0 = ctx.lib.gemm_split_count(ctx.h)
+    out, part = ctx.gemm(a, w, bias=b, res=res, force_tile=1017, gn_partial=True)
+    assert ctx.lib.gemm_split_count(ctx.h) == n0 + 1, "the shape was chosen to trigger the tail split"
+    assert part is not None and torch.equal(out, plain)
+    want = _pair_stats(out, M, N)
+    got = part.double().cpu()
+    scale = want[..., 1].abs().max().item() + 1.0
+    assert (got - want).abs().max().item() <= 2e-5 * scale, (got - want).abs().max().item()
+    gam, bet = torch.randn(N, generator=g), torch.randn(N, generator=g)
+    y = ctx.group_norm_from_partials(out, part, dev(ctx, gam), dev(ctx, bet), M // 4, eps=1e-5, silu=True)
+    y0 = ctx.group_norm(out, dev(ctx, gam), dev(ctx, bet), M // 4, eps=1e-5, silu=True)
+    assert (y.float() - y0.float()).abs().max().item() <= (2e-2 if dtype == torch.bfloat16 else 4e-3) * (1 + y0.float().abs().max().item())
+
+
+def test_group_norm_statistics_with_the_frame_interleaved_walk(ctx, dtype):
+    """ADVICE r05: a temporal conv whose frames are at least one tile row (HW >= 256) walks its tile rows frame-interleaved (gemm.h: t_walk);
+    the statistics epilogue must address the slots of the tile it really computes.  3 frames of 16 x 17 = 272 pixels, 256 x 320 tile."""
+    g = torch.Generator().manual_seed(272)
+    Fr, HW, Cin, Cout = 3, 272, 64, 320
+    M = Fr * HW
+    a = dev(ctx, torch.randn(M, Cin, generator=g).to(dtype))
+    w = dev(ctx, (torch.randn(Cout, 3 * Cin, generator=g) / math.sqrt(3 * Cin)).to(dtype))
+    b = dev(ctx, torch.randn(Cout, generator=g))
+    kw = dict(mode=L.A_TCONV3, temporal=(Fr, HW, Cin))
+    ref3 = ctx.gemm(a, w, bias=b, force_tile=3, **kw)            # 128 x 128 tile: HW >= 128, walked frame-interleaved as well
+    plain = ctx.gemm(a, w, bias=b, force_tile=2, **kw)
+    out, part = ctx.gemm(a, w, bias=b, force_tile=2, gn_partial=True, **kw)
+    assert part is not None and torch.equal(out, plain) and torch.equal(out, ref3)
+    # against the conv itself: y[f] = sum_t W_t x[f + t - 1]
+    x = a.float().cpu().reshape(Fr, HW, Cin)
+    xp = torch.cat([torch.zeros(1, HW, Cin), x, torch.zeros(1, HW, Cin)])
+    wt = w.float().cpu().reshape(Cout, 3, Cin)
+    ref = sum(xp[t:t + Fr] @ wt[:, t].T for t in range(3)) + b.float().cpu()
+    assert_close(out, ref.reshape(M, Cout), dtype, what="tconv (frame-interleaved walk)")
+    want = _pair_stats(out, M, Cout)
+    got = part.double().cpu()
+    scale = want[..., 1].abs().max().item() + 1.0
+    assert (got - want).abs().max().item() <= 2e-5 * scale, (got - want).abs().max().item()
 
 
 ROWSTAT_CASES = [   # tile, (frames, H, W), K, N, residual

@@ -8,6 +8,11 @@ tests/golden/cfg4_small_f2_274x488.pt was produced in the build container by ora
 weights are re-derived here from the same seeds.  The full-width comparison on a whole clip exists at configs[1]'s geometry
 (tests/test_parity_cfg2.py); this fixture pins what only configs[3] has -- its level sizes and N = 133 712 in situ.
 
+Round 6: tests/golden/cfg4_full_f2_274x488.pt is the SAME geometry at FULL WIDTH (`UNetConfig()`: dim 320, 2.04 B parameters, f = 2;
+`python oracle/make_golden_cfg4.py full`, 0.47 PFLOP of fp32 on the CPU): the 320 / 640 / 1280-wide tile choices, the tail splits and the
+tile-17 convs at the level sizes 274 -> 138 -> 70 -> 36, against the reference's own forward.  Bars as at configs[1]'s geometry
+(tests/test_parity_cfg2.py): PSNR over the reference's range >= 50 dB, relative rms <= 1.2e-2; the nominal-peak figure is printed.
+
 Tolerance: relative rms <= 1e-2 against the reference's fp32 output (the whole-forward budget of tests/test_unet.py for fp16
 activations with fp32 accumulation) and PSNR over the reference's range >= 50 dB (north_star's bar).
 """
@@ -23,6 +28,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from util import fmt_metrics, parity_metrics  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden", "cfg4_small_f2_274x488.pt")
+GOLD_FULL = os.path.join(ROOT, "tests", "golden", "cfg4_full_f2_274x488.pt")
 torch.set_grad_enabled(False)
 
 
@@ -71,3 +77,36 @@ def test_hip_forward_matches_the_reference_at_cfg4_geometry():
     assert m["rel_rms"] <= 1e-2 and m["psnr_range"] >= 50.0, m
     again = net(x.to(dev), t=t, y=y.to(dev), hint=hint.to(dev))
     assert torch.equal(out, again)
+
+
+def test_full_width_fixture_is_consistent():
+    """CPU: the full-width fixture matches the generator's configuration and configs[3]'s latent shape."""
+    from make_golden_cfg4 import CFG4_FULL
+    g = torch.load(GOLD_FULL)
+    assert g["cfg"] == CFG4_FULL and CFG4_FULL["width"] == "full" and tuple(CFG4_FULL["latent"]) == (274, 488)
+    assert tuple(g["out"].shape) == (1, 4, CFG4_FULL["frames"], 274, 488) and g["out"].dtype == torch.float32
+    assert torch.isfinite(g["out"]).all() and float(g["out"].std()) > 1e-3
+
+
+@pytest.mark.gpu
+def test_hip_forward_matches_the_reference_at_cfg4_geometry_full_width():
+    """`star_unet_forward` (fp16) at FULL WIDTH on configs[3]'s latent (2 frames x 274 x 488, N = 133 712 keys in the level-0 attention):
+    PSNR(range) >= 50 dB and relative rms <= 1.2e-2 against the reference's own fp32 forward; the nominal-peak figure is printed."""
+    from make_golden import unet_inputs
+    from make_golden_cfg4 import CFG4_FULL
+    from star_amd.modules.unet_v2v import ControlledV2VUNet
+    from star_amd.topology import UNetConfig, random_state_dict
+    gold = torch.load(GOLD_FULL)
+    cfg = UNetConfig()
+    net = ControlledV2VUNet(cfg, dtype=torch.float16, device=0)
+    net.load_state_dict(random_state_dict(cfg, seed=CFG4_FULL["wseed"]))
+    net.release_host_weights()
+    f, (h, w) = CFG4_FULL["frames"], CFG4_FULL["latent"]
+    x, t, y, hint = unet_inputs(cfg, f, h, w, CFG4_FULL["seed"])
+    assert int(t) == gold["t"]
+    dev = torch.device("cuda", 0)
+    out = net(x.to(dev), t=t, y=y.to(dev), hint=hint.to(dev))
+    m = parity_metrics(out.cpu(), gold["out"], nominal_peak=2.0)
+    print(f"cfg4 geometry (2 f, 274x488, FULL width), HIP fp16 vs the reference's fp32: {fmt_metrics(m)}")
+    assert out.shape == gold["out"].shape and torch.isfinite(out).all()
+    assert m["rel_rms"] <= 1.2e-2 and m["psnr_range"] >= 50.0, m

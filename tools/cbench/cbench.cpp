@@ -9,14 +9,21 @@
 //   gemm M N K epi tile[,tile..]   plain-A star_gemm (one line per tile, same operands); epi = STAR_EPI_* bits (1 bias, 2 residual, 4 GEGLU, 32 folded LayerNorm), tile = force_tile
 //   conv NB H W Cin Cout tile      3x3 conv, stride 1, pad 1, bias
 //   tconv F HW C tile              temporal conv (3,1,1), bias + residual
-//   attn B heads Nq Nk             star_attn_fwd (d = 64), K / V per batch
+//   attn B heads Nq Nk [v,v..]     star_attn_fwd (d = 64), K / V per batch; optional list of variant ids (default 9 = product), every
+//                                  variant after the first compared bit for bit with the first one's output
 //   tq F HW                        star_temporal_qkv_attn (C = 320, 5 heads)
 // Output: one line per (spec, tile): min / mean ms per launch over `reps` batches of back-to-back launches (~10 ms each, after
 // >= 150 ms of warm-up launches) and the TFLOP/s of both.
+// Environment: CBENCH_BATCH_MS (default 10) = length of one timed batch; CBENCH_POWER=1 samples the socket's hwmon (power1_average,
+// freq1_input of card 0) every 50 ms during the timed batches and prints mean W / MHz beside the line (use batches >= 500 ms).
 // Test tooling; numbers quoted from it are labelled "cbench" in profiles/.
 #include <dlfcn.h>
 
+#include <atomic>
 #include <chrono>
+#include <thread>
+#include <dirent.h>
+#include <unistd.h>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -118,6 +125,67 @@ static float* rand32(size_t n, float scale, float shift = 0.f) {
   return d;
 }
 
+// socket power / shader clock from sysfs hwmon (never rocm-smi beside a kernel on this pool)
+struct PowerSampler {
+  std::string dir;
+  std::atomic<bool> stop{false};
+  std::thread th;
+  double sw = 0, sf = 0; int n = 0;
+  static bool read_ll(const std::string& path, long long& v) {
+    FILE* f = fopen(path.c_str(), "r");
+    if (!f) return false;
+    const bool ok = fscanf(f, "%lld", &v) == 1;
+    fclose(f);
+    return ok;
+  }
+  // the hwmon directory of the card whose PCI address is HIP device 0's (a box shows every card of the node in sysfs, not only the visible one)
+  PowerSampler() {
+    char want[64] = "";
+#ifndef CBENCH_EMU
+    if (hipDeviceGetPCIBusId(want, sizeof want, 0) != hipSuccess) want[0] = 0;
+    for (char* c = want; *c; ++c) *c = (char)tolower((unsigned char)*c);
+#endif
+    for (int card = 0; card < 128 && dir.empty(); ++card) {
+      const std::string dev = "/sys/class/drm/card" + std::to_string(card) + "/device";
+      char link[512];
+      const ssize_t n = readlink(dev.c_str(), link, sizeof link - 1);
+      if (n <= 0) continue;
+      link[n] = 0;
+      if (want[0] && !strstr(link, want)) continue;
+      const std::string base = dev + "/hwmon";
+      if (DIR* d = opendir(base.c_str())) {
+        while (dirent* e = readdir(d)) {
+          if (strncmp(e->d_name, "hwmon", 5)) continue;
+          long long v;
+          const std::string h = base + "/" + e->d_name;
+          if (read_ll(h + "/power1_average", v) || read_ll(h + "/power1_input", v)) { dir = h; break; }
+        }
+        closedir(d);
+      }
+    }
+    if (dir.empty()) fprintf(stderr, "cbench: no hwmon found for device %s\n", want);
+  }
+  void start() {
+    if (dir.empty()) return;
+    stop = false; sw = sf = 0; n = 0;
+    th = std::thread([this] {
+      while (!stop) {
+        long long pw = 0, fq = 0;
+        if (!read_ll(dir + "/power1_average", pw)) read_ll(dir + "/power1_input", pw);
+        read_ll(dir + "/freq1_input", fq);
+        sw += pw * 1e-6; sf += fq * 1e-6; ++n;
+        std::this_thread::sleep_for(std::chrono::milliseconds(50));
+      }
+    });
+  }
+  void finish(double& w, double& mhz) {
+    w = mhz = 0;
+    if (dir.empty()) return;
+    stop = true; th.join();
+    if (n) { w = sw / n; mhz = sf / n; }
+  }
+};
+
 struct Timer {
 #ifndef CBENCH_EMU
   hipStream_t stream;
@@ -134,7 +202,9 @@ struct Timer {
 #ifdef CBENCH_EMU
     const double warm_ms = 0.0, batch_ms = 0.0;
 #else
-    const double warm_ms = 150.0, batch_ms = 10.0;
+    const double warm_ms = 150.0, batch_ms = getenv("CBENCH_BATCH_MS") ? atof(getenv("CBENCH_BATCH_MS")) : 10.0;
+    const bool power = getenv("CBENCH_POWER") != nullptr;
+    PowerSampler ps;
 #endif
     auto t0 = now();
     int nwarm = 0;
@@ -143,6 +213,9 @@ struct Timer {
     int inner = est > 0 ? (int)(batch_ms / est + 0.5) : 1;
     if (inner < 1) inner = 1;
     double mn = 1e30, sum = 0;
+#ifndef CBENCH_EMU
+    if (power) ps.start();
+#endif
     for (int i = 0; i < reps; ++i) {
 #ifdef CBENCH_EMU
       auto t1 = now();
@@ -160,8 +233,12 @@ struct Timer {
       mn = ms < mn ? ms : mn; sum += ms;
     }
     const double mean = sum / reps;
-    printf("%-44s min %8.4f ms  mean %8.4f ms  %8.1f TFLOP/s (mean)  %8.1f (min)  [%d x %d]\n", label, mn, mean, flops / (mean * 1e-3) * 1e-12,
+    printf("%-44s min %8.4f ms  mean %8.4f ms  %8.1f TFLOP/s (mean)  %8.1f (min)  [%d x %d]", label, mn, mean, flops / (mean * 1e-3) * 1e-12,
            flops / (mn * 1e-3) * 1e-12, reps, inner);
+#ifndef CBENCH_EMU
+    if (power) { double w, mhz; ps.finish(w, mhz); printf("  %6.0f W %5.0f MHz", w, mhz); }
+#endif
+    printf("\n");
     fflush(stdout);
   }
 };
@@ -275,6 +352,9 @@ int main(int argc, char** argv) {
       dev_free(A); dev_free(W); dev_free(C); if (R) dev_free(R); dev_free(bias); dev_free(colsum); if (rowab) dev_free(rowab);
     } else if (kind == "attn") {
       long long B, heads, Nq, Nk; in >> B >> heads >> Nq >> Nk;
+      std::vector<int> variants;
+      { std::string vs; if (in >> vs) { std::istringstream ts(vs); std::string tk; while (std::getline(ts, tk, ',')) if (!tk.empty()) variants.push_back(atoi(tk.c_str())); } }
+      if (variants.empty()) variants.push_back(9);
       const long long Cw = heads * 64;
       void* Q = rand16((size_t)B * Nq * Cw, 1.0f);
       void* Kp = rand16((size_t)B * Nk * Cw, 1.0f);
@@ -284,8 +364,28 @@ int main(int argc, char** argv) {
       d.Q = Q; d.K = Kp; d.V = V; d.O = O; d.ldq = d.ldk = d.ldv = d.ldo = (int)Cw;
       d.bsq = d.bso = Nq * Cw; d.bsk = d.bsv = Nk * Cw;
       d.Nq = (int)Nq; d.Nk = (int)Nk; d.heads = (int)heads; d.batch = (int)B; d.scale = 0.125f; d.variant = 9;
-      snprintf(label, sizeof label, "attn B=%lld heads=%lld Nq=%lld Nk=%lld", B, heads, Nq, Nk);
-      T.run(label, 4.0 * B * heads * (double)Nq * Nk * 64.0, reps, [&] { return api.attn_fwd(ctx, &d); });
+      std::vector<uint16_t> first, cur;
+      for (size_t vi = 0; vi < variants.size(); ++vi) {
+        d.variant = variants[vi];
+        snprintf(label, sizeof label, "attn B=%lld heads=%lld Nq=%lld Nk=%lld v=%d", B, heads, Nq, Nk, d.variant);
+        T.run(label, 4.0 * B * heads * (double)Nq * Nk * 64.0, reps, [&] { return api.attn_fwd(ctx, &d); });
+        if (variants.size() > 1) {
+          std::vector<uint16_t>& dst = vi == 0 ? first : cur;
+          dst.resize((size_t)B * Nq * Cw);
+          api.sync(ctx);
+          download(dst.data(), O, dst.size() * 2);
+          if (vi > 0) {
+            size_t bad = 0;
+            for (size_t i = 0; i < cur.size(); ++i) bad += cur[i] != first[i];
+            printf("    variant %d vs variant %d: %zu of %zu outputs differ%s\n", d.variant, variants[0], bad, cur.size(), bad ? "" : " (bit-identical)");
+          }
+#ifndef CBENCH_EMU
+          HCHECK(hipMemset(O, 0xFF, dst.size() * 2));
+#else
+          memset(O, 0xFF, dst.size() * 2);
+#endif
+        }
+      }
       dev_free(Q); dev_free(Kp); dev_free(V); dev_free(O);
     } else if (kind == "tq") {
       long long Fr, HW; in >> Fr >> HW;

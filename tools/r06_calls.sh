@@ -1,0 +1,45 @@
+#!/bin/bash
+# Round-6 GPU calls: each block is ONE gpurun call; run from the repo root on the GPU box (gpurun -- 'bash tools/r06_calls.sh 1').
+# Outputs under gpurun_out/ (what is quoted is copied into profiles/, index in profiles/README.md).
+set -u
+mkdir -p gpurun_out
+R=${GRAFT_REPO_ROOT:-/root/repo}
+BL=$R/tools/bench/libstar_hip_bench.so
+case "${1:-1}" in
+  1)  # (a) attention: one 512-thread workgroup per CU (variant 34) against the product kernel, with socket power / clock beside it;
+      # (b) the traffic table: per (family, shape) >= 3 ms of a cfg2 forward, three single-group PMC passes on the torch-free harness
+      CBENCH_POWER=1 CBENCH_BATCH_MS=700 timeout 120 ./tools/cbench/cbench $BL f16 - 4 > gpurun_out/r06_attn8_ab.txt 2>&1 <<'SPEC'
+attn 32 5 26352 26352 9,34,9,34
+attn 32 10 6696 6696 9,34
+attn 32 20 1728 1728 9,34
+attn 32 5 26352 77 9,34
+SPEC
+      cat gpurun_out/r06_attn8_ab.txt
+      timeout 200 ./tools/cbench/cbench $BL f16 tools/cbench/r06_traffic_shapes.txt 6 > gpurun_out/r06_traffic_timing.txt 2>&1
+      cd /tmp && export TMPDIR=/tmp
+      P=$R/gpurun_out/r06_pmc; rm -rf $P; mkdir -p $P
+      i=0
+      grep -v '^#' $R/tools/cbench/r06_traffic_shapes.txt | grep -v '^\s*$' | while read -r line; do
+        echo "$line" > /tmp/one.txt
+        timeout 60 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $P/s${i}_FETCH -- $R/tools/cbench/cbench $BL f16 /tmp/one.txt 1 > $P/s${i}_FETCH.log 2>&1
+        timeout 60 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $P/s${i}_WRITE -- $R/tools/cbench/cbench $BL f16 /tmp/one.txt 1 > $P/s${i}_WRITE.log 2>&1
+        timeout 60 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE -d $P/s${i}_SQ -- $R/tools/cbench/cbench $BL f16 /tmp/one.txt 1 > $P/s${i}_SQ.log 2>&1
+        i=$((i+1))
+      done
+      cd $R
+      python tools/pmc_traffic_table.py tools/cbench/r06_traffic_shapes.txt gpurun_out/r06_pmc gpurun_out/r06_traffic_timing.txt > gpurun_out/r06_traffic_table.txt 2>&1
+      cat gpurun_out/r06_traffic_table.txt
+      find gpurun_out/r06_pmc -name "*.db" -size +2M -delete; du -sh gpurun_out/r06_pmc ;;
+  2)  # (a) the attention A/B again with the socket's own hwmon beside it; (b) tile 18's walk / store policy and the two-workgroup GEGLU tile;
+      # (c) what a B = 2 batched CFG pair could buy at levels 2-3; (d) the new unit tests on hardware
+      CBENCH_POWER=1 CBENCH_BATCH_MS=800 timeout 120 ./tools/cbench/cbench $BL f16 - 3 > gpurun_out/r06_attn8_ab_power.txt 2>&1 <<'SPEC'
+attn 32 5 26352 26352 9,34,9,34
+SPEC
+      cat gpurun_out/r06_attn8_ab_power.txt
+      timeout 300 ./tools/cbench/cbench $BL f16 tools/cbench/r06_persist_walk.txt 6 > gpurun_out/r06_cbench_persist_walk.txt 2>&1
+      grep -v "bit-identical" gpurun_out/r06_cbench_persist_walk.txt | cut -c1-120
+      timeout 300 ./tools/cbench/cbench $BL f16 tools/cbench/r06_cfg_batch.txt 6 > gpurun_out/r06_cbench_cfg_batch.txt 2>&1
+      cut -c1-100 gpurun_out/r06_cbench_cfg_batch.txt
+      timeout 900 python -m pytest tests/test_kernels.py -m gpu -x -q -k "tail_split or frame_interleaved or flash_attention_self or producer_epilogue" 2>&1 | tail -5 > gpurun_out/r06_pytest_new1.txt
+      cat gpurun_out/r06_pytest_new1.txt ;;
+esac
