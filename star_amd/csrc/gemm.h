@@ -308,7 +308,9 @@ gemm_kernel(const GemmParams p) {
       // holds.  With the channel blocks inside a tap (the order until round 5) a line came back five K tiles x 32 workgroups later: every
       // tap was fetched from beyond the L2, 5.0 GB per level-0 launch against 0.54 GB of input (profiles/r05_pmc_kernels.txt);
       // -7.8 % / -3.8 % / -1.4 % at the 320 / 640 / 1280-wide levels (profiles/r05_cbench_conv_korder.txt).  The temporal conv's taps are
-      // whole frames apart (no reuse within reach of any cache): it keeps tap-major order (channel-major measured +1-3 % slower).
+      // whole frames apart: it keeps tap-major order.  Channel-major measured 1-3 % slower with the row-major walk (round 5); with the
+      // frame-interleaved walk (t_walk) it cuts the level-0 launch's FETCH_SIZE by 38 % and buys +2.2 % there, 0 at level 1, -2 % at levels
+      // 2-3 (profiles/r06_cbench_tconv_korder.txt): 0.06 % of a forward, not worth a second weight layout -- measured and dropped in round 6.
       if constexpr (AMODE == A_TCONV3) {
         c0 += BK;
         if (c0 >= p.Cin) { c0 = 0; ++tap; }

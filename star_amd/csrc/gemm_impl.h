@@ -169,9 +169,10 @@ static int launch_gemm(Ctx* ctx, const GemmArgs& a) {
       return launch_gemm<T>(ctx, b);
     }
   }
-  // GroupNorm statistics in the epilogue: the flavour exists for tiles 2, 3 and 17 on plain / 3x3 / temporal-conv layers with the
-  // bias (+ residual) 16-bit epilogue; elsewhere the request is dropped (gn_done stays false: the consumer runs its own pass)
-  if (a.gn_partial && (!(tile == 2 || tile == 3 || tile == 17) || (tile == 17 && (a.epi & EPI_RES)) || !(a.mode == A_PLAIN || a.mode == A_CONV3X3 || a.mode == A_TCONV3) ||
+  // GroupNorm statistics in the epilogue: the flavour exists for tiles 1-4 and 17 on plain / 3x3 / temporal-conv layers with the
+  // bias (+ residual) 16-bit epilogue (round 6: + the power-of-two tiles 1 and 4, which run the VAE's 128 / 256 / 512-wide layers);
+  // elsewhere the request is dropped (gn_done stays false: the consumer runs its own pass)
+  if (a.gn_partial && (!(tile == 1 || tile == 2 || tile == 3 || tile == 4 || tile == 17) || (tile == 17 && (a.epi & EPI_RES)) || !(a.mode == A_PLAIN || a.mode == A_CONV3X3 || a.mode == A_TCONV3) ||
                        (a.epi & (EPI_OUT_F32 | EPI_ROWAFF | EPI_GELU_TANH | EPI_GEGLU)) || (a.N & 7))) {
     GemmArgs b = a;
     b.gn_partial = nullptr;
@@ -212,14 +213,14 @@ static int launch_gemm(Ctx* ctx, const GemmArgs& a) {
   switch (tile) {
     // 8 waves per workgroup (2 per SIMD, <= 256 VGPRs each; 192 / 236 used, no spills): measured 1.3-3.6x faster than
     // 4-wave variants of the same tiles on the K = 320 layers (profiles/r01_gemm_tile_sweep.txt)
-    case 1: return launch_gemm_t<T, 256, 256, 4, 2, 2, false, 0, true>(ctx, a);
+    case 1: return launch_gemm_t<T, 256, 256, 4, 2, 2, false, 0, true, true>(ctx, a);
     case 2: return launch_gemm_t<T, 256, 320, 4, 2, 2, false, 0, true, true>(ctx, a);
     // 4 waves x (128 x 128), one wave per SIMD, hand-placed 2-stage loop (gemm.h SCHED): plain / 3x3 conv / temporal conv, 16-bit output
     case 17:
       if (a.epi & (EPI_OUT_F32 | EPI_ROWAFF | EPI_GELU_TANH | EPI_GEGLU)) return ctx->fail("gemm: tile 17 has the plain and residual 16-bit epilogues only");
       return launch_gemm_f<T, 256, 256, 2, 2, 1, false, false, 0, false, 1, 0, true>(ctx, a);
     case 18: return launch_gemm_persist(ctx, a);   // persistent one-wave-per-SIMD tile with a wave-private epilogue (gemm_p.h)
-#ifdef STAR_BENCH_VARIANTS   // round-6 A/Bs of tile 18's walk and store policy (bit-identical): 60 = non-temporal stores (+ 66: on column strips of 8);
+#ifdef STAR_BENCH_VARIANTS   // round-6 A/Bs of tile 18's walk and store policy (bit-identical): 60 = PLAIN stores, the round-5 kernel (the product stores non-temporally since round 6; + 66: plain stores on column strips of 8);
     // 61 / 62 / 63 = row groups of 1 / 4 / 16 (product: 8 where a tile row is >= 12 tiles wide); 64 / 65 / 67 = column strips of 8 / 4 / 16
     case 60: return launch_gemm_persist(ctx, a);
     // 69 = tile 9 (two independent 4-wave workgroups per CU on 128 x 256 tiles: one group's GEGLU epilogue runs beside the other's K loop)
@@ -234,7 +235,7 @@ static int launch_gemm(Ctx* ctx, const GemmArgs& a) {
     }
 #endif
     case 3: return launch_gemm_t<T, 128, 128, 2, 2, 2, false, 0, true, true>(ctx, a);
-    case 4: return launch_gemm_t<T, 256, 128, 4, 1, 1, false, 0, true>(ctx, a);
+    case 4: return launch_gemm_t<T, 256, 128, 4, 1, 1, false, 0, true, true>(ctx, a);
 #ifdef STAR_BENCH_VARIANTS   // A/B experiments of round 1 / 2 that lost to the tiles above (profiles/r01_gemm_ablation.txt, r02_gemm8_ablation.txt)
     case 5: return launch_gemm_t<T, 256, 256, 4, 2, 2, true>(ctx, a);   // staggered wave groups (A/B)
     // (the 256x320 tile has no room for the carried fragments: 730+ VGPR spills when staggered)

@@ -31,21 +31,25 @@ static int launch_persist_t(Ctx* ctx, const GemmArgs& a) {
   if (G >= 8) G &= ~7;
   constexpr size_t smem = 2 * (size_t)(256 + 256) * 128 + 4 * (size_t)4096 + 2 * (size_t)2048;
   const dim3 grid((unsigned)G), block(256);
-#ifdef STAR_BENCH_VARIANTS   // round-6 A/B (correct results, bit-identical): 60 = non-temporal output stores
+#ifdef STAR_BENCH_VARIANTS   // round-6 A/B reference (bit-identical): 60 = the round-5 kernel's plain output stores
   if (a.force_tile == 60) {
-    if ((a.epi & EPI_ROWAFF) && (a.epi & EPI_GEGLU)) STAR_LAUNCH((gemm_persist_kernel<T, 10, 2>), grid, block, smem, ctx->stream, p);
-    else if (a.epi & EPI_GEGLU) STAR_LAUNCH((gemm_persist_kernel<T, 2, 2>), grid, block, smem, ctx->stream, p);
-    else if (a.epi & EPI_ROWAFF) STAR_LAUNCH((gemm_persist_kernel<T, 8, 2>), grid, block, smem, ctx->stream, p);
-    else if (a.epi & EPI_RES) STAR_LAUNCH((gemm_persist_kernel<T, 1, 2>), grid, block, smem, ctx->stream, p);
-    else STAR_LAUNCH((gemm_persist_kernel<T, 0, 2>), grid, block, smem, ctx->stream, p);
+    if ((a.epi & EPI_ROWAFF) && (a.epi & EPI_GEGLU)) STAR_LAUNCH((gemm_persist_kernel<T, 10, 0>), grid, block, smem, ctx->stream, p);
+    else if (a.epi & EPI_GEGLU) STAR_LAUNCH((gemm_persist_kernel<T, 2, 0>), grid, block, smem, ctx->stream, p);
+    else if (a.epi & EPI_ROWAFF) STAR_LAUNCH((gemm_persist_kernel<T, 8, 0>), grid, block, smem, ctx->stream, p);
+    else if (a.epi & EPI_RES) STAR_LAUNCH((gemm_persist_kernel<T, 1, 0>), grid, block, smem, ctx->stream, p);
+    else STAR_LAUNCH((gemm_persist_kernel<T, 0, 0>), grid, block, smem, ctx->stream, p);
     return 0;
   }
 #endif
-  if ((a.epi & EPI_ROWAFF) && (a.epi & EPI_GEGLU)) STAR_LAUNCH((gemm_persist_kernel<T, 10>), grid, block, smem, ctx->stream, p);
-  else if (a.epi & EPI_GEGLU) STAR_LAUNCH((gemm_persist_kernel<T, 2>), grid, block, smem, ctx->stream, p);
-  else if (a.epi & EPI_ROWAFF) STAR_LAUNCH((gemm_persist_kernel<T, 8>), grid, block, smem, ctx->stream, p);
-  else if (a.epi & EPI_RES) STAR_LAUNCH((gemm_persist_kernel<T, 1>), grid, block, smem, ctx->stream, p);
-  else STAR_LAUNCH((gemm_persist_kernel<T, 0>), grid, block, smem, ctx->stream, p);
+  // the product form stores NON-TEMPORALLY (STPOL 2): the 0.4-1.1 GB output streams past the L2 instead of evicting the operand panels the
+  // resident workgroups of an XCD share.  cbench A/B on one box, bit-identical (profiles/r06_cbench_persist_walk.txt): GEGLU level 1
+  // +1.8 %, level 2 +2.2 %, q | k | v level 2 +4.5 %, stem 4096 x 512 +1.4 %.  (The TILED kernels' epilogues gain nothing from it:
+  // profiles/r05_cbench_gemm_nt.txt.)
+  if ((a.epi & EPI_ROWAFF) && (a.epi & EPI_GEGLU)) STAR_LAUNCH((gemm_persist_kernel<T, 10, 2>), grid, block, smem, ctx->stream, p);
+  else if (a.epi & EPI_GEGLU) STAR_LAUNCH((gemm_persist_kernel<T, 2, 2>), grid, block, smem, ctx->stream, p);
+  else if (a.epi & EPI_ROWAFF) STAR_LAUNCH((gemm_persist_kernel<T, 8, 2>), grid, block, smem, ctx->stream, p);
+  else if (a.epi & EPI_RES) STAR_LAUNCH((gemm_persist_kernel<T, 1, 2>), grid, block, smem, ctx->stream, p);
+  else STAR_LAUNCH((gemm_persist_kernel<T, 0, 2>), grid, block, smem, ctx->stream, p);
   return 0;
 }
 

@@ -25,7 +25,7 @@
 
 namespace star {
 
-// STPOL: cache policy of the output stores (prim.h: buf_store16_pol; 0 = plain, 2 = non-temporal) -- round-6 A/B, bench build only
+// STPOL: cache policy of the output stores (prim.h: buf_store16_pol; 2 = non-temporal, the product since round 6; 0 = plain, the round-5 form, bench build only)
 template <class T, int EPIF, int STPOL = 0>   // EPIF: bit 0 residual add, bit 1 GEGLU (weight rows in 32-row (value, gate) blocks), bit 3 row-affine (folded LayerNorm); 16-bit output
 STAR_GLOBAL void STAR_LAUNCH_BOUNDS(256, 1)
 gemm_persist_kernel(const GemmParams p) {

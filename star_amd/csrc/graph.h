@@ -232,6 +232,51 @@ struct Builder {
         }
     return fold_ln(r, rb, N2, K, norm);
   }
+  // FeedForward's second Linear and the transformer's proj_out are both affine maps of the SAME rows with only a residual between them:
+  //   out = proj_out(ff2(g) + h2) + x_in = [W_po | W_po W_ff2] [h2 ; g] + (b_po + W_po b_ff2) + x_in            (unet_v2v.py:316,489-490,526-529)
+  // so one GEMM over the concatenated operand [h2 | g] (K = 5 x inner) replaces two, and h3 = ff2(g) + h2 (one write + one read of the
+  // activation) never exists.  The composite weight is computed ON THE DEVICE at build time from the 16-bit weights the two GEMMs would
+  // have multiplied by, in ONE launch: W_po [I ; W_ff2^T]^T (fp32 accumulation, rounded once; the identity block reproduces W_po
+  // exactly); the bias in fp32 on the host.  Round 6.
+  LinW compose_ff2_proj_out(const std::string& ff2, const std::string& po) {
+    LinW l;
+    const HostTensor* w2 = get(ff2 + ".weight"); const HostTensor* b2 = get(ff2 + ".bias");
+    const HostTensor* wp = get(po + ".weight"); const HostTensor* bp = get(po + ".bias");
+    if (!w2 || !b2 || !wp || !bp) return l;
+    const int inner = (int)w2->shape[0], hid = (int)(w2->data.size() / (size_t)inner);
+    const int Co = (int)wp->shape[0];
+    if ((int)(wp->data.size() / (size_t)Co) != inner) { if (err.empty()) err = "compose_ff2_proj_out: proj_out's input width must be ff's output width (" + po + ")"; return l; }
+    const int Kc = inner + hid;
+    std::vector<float> e((size_t)Kc * inner, 0.f), rb(Co);
+    for (int i = 0; i < inner; ++i) e[(size_t)i * inner + i] = 1.0f;
+    for (int j = 0; j < inner; ++j)
+      for (int k = 0; k < hid; ++k) e[(size_t)(inner + k) * inner + j] = w2->data[(size_t)j * hid + k];
+    for (int n = 0; n < Co; ++n) {
+      double acc = bp->data[n];
+      for (int j = 0; j < inner; ++j) acc += (double)wp->data[(size_t)n * inner + j] * b2->data[j];
+      rb[n] = (float)acc;
+    }
+    // temporaries of the build (freed right after the launch has completed)
+    std::vector<void*> tmp;
+    std::vector<void*>* keep = owned;
+    owned = &tmp;
+    const DevW ed = upload_T(e), pd = upload_T(wp->data);
+    owned = keep;
+    l.N = Co; l.K = Kc;
+    l.w.n = (int64_t)Co * Kc;
+    int rc = 1;
+    if (ed.p && pd.p && !rt::dev_malloc(&l.w.p, (size_t)Co * Kc * 2 + 256)) {
+      owned->push_back(l.w.p);
+      GemmArgs g;
+      g.A = pd.p; g.W = ed.p; g.C = l.w.p; g.M = Co; g.N = Kc; g.K = inner; g.lda = inner; g.ldc = Kc;
+      rc = op_gemm(ctx, g);
+      rt::stream_sync(ctx->stream);
+    }
+    for (void* q : tmp) rt::dev_free(q);
+    if (rc) { if (err.empty()) err = "compose_ff2_proj_out: composing " + po + " failed"; return LinW{}; }
+    l.b = upload_f32(rb);
+    return l;
+  }
   DevW raw_f32(const std::string& name) {
     const HostTensor* t = get(name);
     return t ? upload_f32(t->data) : DevW{};
@@ -241,6 +286,8 @@ struct Builder {
 
 struct Act {          // an activation tensor: rows = F*H*W tokens; the buffer returns to the pool with its last owner
   std::shared_ptr<Buf> buf; int C = 0, H = 0, W = 0;
+  int ld = 0;          // row stride in elements when the rows live inside a wider buffer (Runner::make_wide); 0 = dense (C)
+  int ldv() const { return ld ? ld : C; }
   // GroupNorm partial statistics of THIS tensor, written by the kernel that produced it (GemmArgs::gn_partial): a GroupNorm that
   // reads the tensor finalizes from them instead of running its own statistics pass; null = none
   std::shared_ptr<Buf> gnp;
@@ -263,6 +310,14 @@ struct Runner {
   Act make(int C, int H, int W) {
     Act a; a.C = C; a.H = H; a.W = W;
     a.buf = std::make_shared<Buf>(ctx, (size_t)F * H * W * C * es);
+    if (!a.buf->p) { rc = ctx->fail("out of device memory (activations)"); }
+    return a;
+  }
+  // C columns at the head of rows of `ld` elements: the tail (ld - C columns per row) belongs to the caller (Fwd::ff_and_out keeps the
+  // GEGLU output there, so that [h2 | g] is ONE operand of the composed FF-out / proj_out GEMM)
+  Act make_wide(int C, int H, int W, int ld) {
+    Act a; a.C = C; a.H = H; a.W = W; a.ld = ld;
+    a.buf = std::make_shared<Buf>(ctx, (size_t)F * H * W * ld * es);
     if (!a.buf->p) { rc = ctx->fail("out of device memory (activations)"); }
     return a;
   }
@@ -340,7 +395,7 @@ struct Runner {
     if (x.lnp && x.lnp->p && x.ln_parts > 0)
       ok(op_layer_norm_from_partials(ctx, x.lnp->as<float>(), x.ln_parts, rws, C, 1e-5f, mode, gw, maps, H, W, rowab));
     else
-      ln_rows(x.p(), rowab, rws, C, mode, gw, maps, H, W);
+      ok(op_layer_norm(ctx, x.p(), x.ldv(), nullptr, C, nullptr, nullptr, rws, C, 1e-5f, mode, gw, maps, H, W, rowab));
   }
   // y = LN(x) W^T + b through the folded form (w built by Builder::*_ln)
   void gemm_ln(const void* A, int lda, int M, const LinW& w, const float* rowab, void* C, int ldc, int extra_epi = 0) {

@@ -72,6 +72,7 @@ struct UBuilder : Builder {
     s.norm = norm(p + ".norm"); s.C = s.norm.C; s.heads = heads;
     s.proj_in = linear(p + ".proj_in"); s.proj_out = linear(p + ".proj_out");
     s.tb = tblock(p + ".transformer_blocks.0", true);
+    s.tb.ffpo = compose_ff2_proj_out(p + ".transformer_blocks.0.ff.net.2", p + ".proj_out");
     return s;
   }
   TTW tt(const std::string& p, int heads) {
@@ -80,6 +81,7 @@ struct UBuilder : Builder {
     s.proj_in = linear(p + ".proj_in"); s.proj_out = linear(p + ".proj_out");
     s.inner = s.proj_in.N;
     s.tb = tblock(p + ".transformer_blocks.0", false);
+    s.tb.ffpo = compose_ff2_proj_out(p + ".transformer_blocks.0.ff.net.2", p + ".proj_out");
     return s;
   }
 };
@@ -129,10 +131,27 @@ struct Fwd : Runner {
     return cur;
   }
 
-  // shared tail of both transformer kinds: LN3 -> GEGLU FF -> +res ; then proj_out (+ x_in)
+  // shared tail of both transformer kinds: LN3 -> GEGLU FF -> +res ; then proj_out (+ x_in).
+  // Round 6: ff2 (+ h2) and proj_out are ONE GEMM over the operand [h2 | g] with the composed weight (graph.h: compose_ff2_proj_out):
+  // h2 is allocated by make_h2() as the head of rows of 5 x inner elements, the GEGLU projection writes g behind it.  h3 = ff2(g) + h2
+  // is never written or read (level 0: 1.1 GB per block).  STAR_NO_FFPO=1: the two GEMMs of rounds 1-5 (A/B switch, read once).
+  static bool ffpo_enabled() { static const bool v = std::getenv("STAR_NO_FFPO") == nullptr; return v; }
+  Act make_h2(const TBlockW& tb, int inner, int H, int W) {
+    if (ffpo_enabled() && tb.ffpo.w.p && tb.ffpo.K == 5 * inner) return make_wide(inner, H, W, 5 * inner);
+    return make(inner, H, W);
+  }
   void ff_and_out(const TBlockW& tb, Act& h2, int R, int inner, const LinW& proj_out, const Act& x_in, Act& out) {
     Buf ab(ctx, (size_t)R * 2 * 4);
     ln_rows(h2, ab.as<float>(), R, inner);                             // norm3, folded into the GEGLU projection (row statistics from h2's producer where it left them)
+    if (h2.ld == 5 * inner) {
+      if (!ab.p) { rc = ctx->fail("out of device memory (ff)"); return; }
+      char* gp = (char*)h2.p() + (size_t)inner * es;                   // g = columns [inner, 5 inner) of h2's rows
+      gemm_ln(h2.p(), h2.ld, R, tb.ff1, ab.as<float>(), gp, h2.ld, EPI_GEGLU);
+      ab.reset();
+      gemm(h2.p(), h2.ld, R, tb.ffpo, out.p(), out.C, x_in.p(), x_in.C, 0, nullptr, want_out_stats ? &out : nullptr);
+      h2.drop();
+      return;
+    }
     Buf g(ctx, (size_t)R * inner * 4 * es);
     if (!g.p || !ab.p) { rc = ctx->fail("out of device memory (ff)"); return; }
     gemm_ln(h2.p(), inner, R, tb.ff1, ab.as<float>(), g.p, inner * 4, EPI_GEGLU);
@@ -200,8 +219,8 @@ struct Fwd : Runner {
       ok(op_flash_attn(ctx, a));
     }
     q2.drop(); kv.reset();
-    Act h2 = make(C, x.H, x.W);
-    gemm(n.p(), C, R, tb.out2, h2.p(), C, mid.h1.p(), C, 0, nullptr, nullptr, &h2);   // + h2's row statistics (norm3)
+    Act h2 = make_h2(tb, C, x.H, x.W);
+    gemm(n.p(), C, R, tb.out2, h2.p(), h2.ldv(), mid.h1.p(), C, 0, nullptr, nullptr, &h2);   // + h2's row statistics (norm3)
     n.drop();
     Act out = make(C, x.H, x.W);
     ff_and_out(tb, h2, R, C, s.proj_out, x, out);
@@ -260,8 +279,8 @@ struct Fwd : Runner {
       a.ldq = a.ldk = a.ldv = 3 * I; a.ldo = I; a.F = F; a.HW = HW; a.heads = s.heads; a.scale = 0.125f;
       ok(op_temporal_attn(ctx, a));
       }
-      Act nx = make(I, x.H, x.W);
-      gemm(l.p(), I, R, pass == 0 ? tb.out1 : tb.out2, nx.p(), I, cur.p(), I, 0, nullptr, nullptr, &nx);   // + nx's row statistics (next pass / norm3)
+      Act nx = pass == 0 ? make(I, x.H, x.W) : make_h2(tb, I, x.H, x.W);     // the second pass's output is the FeedForward's h2
+      gemm(l.p(), I, R, pass == 0 ? tb.out1 : tb.out2, nx.p(), nx.ldv(), cur.p(), I, 0, nullptr, nullptr, &nx);   // + nx's row statistics (next pass / norm3)
       cur = std::move(nx);
     }
     qkv.reset(); l.drop(); ab.reset();

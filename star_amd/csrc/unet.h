@@ -32,6 +32,7 @@ struct TBlockW {
   LinW qkv1_tq, qkv2_tq;  // temporal blocks of width 320: the same projections with their 64-row tiles ordered (q_h, k_h, v_h) per head, for
                           // the fused projection + attention kernel (gemm_tq.h); empty elsewhere
   LinW ff1, ff2;         // ff1 GEGLU-interleaved
+  LinW ffpo;             // [W_po | W_po W_ff2] over the operand [h2 | g]: ff2 (+ h2) and the transformer's proj_out in one GEMM (graph.h: compose_ff2_proj_out)
   DevW local1, local2;   // fp32 LIEM gate weights
 };
 struct STW { int C = 0, heads = 0; NormW norm; LinW proj_in, proj_out; TBlockW tb; };

@@ -63,12 +63,17 @@ struct VBuilder : Builder {
 };
 
 struct VRun : Runner {
+  // GroupNorm statistics leave with the data (round 6, as in the UNet since round 5: gemm.h EPIF bit 4): every conv / temporal conv /
+  // projection whose output is read by a GroupNorm next also writes that tensor's partial statistics, and the norm finalizes from them
+  // instead of reading the tensor twice.  out_stats: the module BEHIND the running one starts with a GroupNorm of its output (set by the
+  // block walkers below; false in front of a Downsample / Upsample conv).
+  bool out_stats = true;
   // ResnetBlock2D without time embedding (eps 1e-6): x + conv2(silu(gn(conv1(silu(gn(x))))))
-  Act res2d(const Res2DW& r, Act x) {
+  Act res2d(const Res2DW& r, Act x, bool stats_out) {
     Act n1 = make(r.cin, x.H, x.W);
     gn(x, r.n1, n1, false, 1e-6f, true);
     Act h1 = make(r.cout, x.H, x.W);
-    conv3x3(n1, r.c1, h1, A_CONV3X3, 1, 1, 1, nullptr);
+    conv3x3(n1, r.c1, h1, A_CONV3X3, 1, 1, 1, nullptr, nullptr, 0, nullptr, 0, 1, true);   // + h1's partials (norm2)
     n1.drop();
     Act n2 = make(r.cout, x.H, x.W);
     gn(h1, r.n2, n2, false, 1e-6f, true);
@@ -77,31 +82,31 @@ struct VRun : Runner {
     const void* sp = x.p();
     if (r.has_sc) { sc = make(r.cout, x.H, x.W); gemm(x.p(), x.C, rows(x), r.sc, sc.p(), r.cout); sp = sc.p(); }
     Act y = make(r.cout, x.H, x.W);
-    conv3x3(n2, r.c2, y, A_CONV3X3, 1, 1, 1, sp);
+    conv3x3(n2, r.c2, y, A_CONV3X3, 1, 1, 1, sp, nullptr, 0, nullptr, 0, 1, stats_out);
     return y;
   }
+  Act res2d(const Res2DW& r, Act x) { return res2d(r, std::move(x), out_stats); }
   // SpatioTemporalResBlock: spatial resnet, TemporalResnetBlock over the frame axis (GN stats over the whole group,
   // eps 1e-5), AlphaBlender folded into tc2
   Act stres(const STResW& s, Act x) {
-    Act xs = res2d(s.sp, std::move(x));
-    const int C = xs.C, R = rows(xs);
+    Act xs = res2d(s.sp, std::move(x), true);          // + xs's partials (the temporal block's norm1, over the whole group)
+    const int C = xs.C;
     Act n1 = make(C, xs.H, xs.W);
     gn(xs, s.tn1, n1, true, 1e-5f, true);
     Act h1 = make(C, xs.H, xs.W);
-    tconv(n1, s.tc1, h1, nullptr);
+    tconv(n1, s.tc1, h1, nullptr, true);               // + h1's partials (norm2)
     gn(h1, s.tn2, n1, true, 1e-5f, true);
     Act y = make(C, xs.H, xs.W);
-    tconv(n1, s.tc2, y, xs.p());
-    (void)R;
+    tconv(n1, s.tc2, y, xs.p(), out_stats);
     return y;
   }
-  void tconv(const Act& x, const LinW& w, Act& y, const void* res) {
+  void tconv(const Act& x, const LinW& w, Act& y, const void* res, bool stats) {
     GemmArgs g;
     g.A = x.p(); g.W = w.w.p; g.C = y.p(); g.M = rows(x); g.N = w.N; g.K = w.K; g.lda = x.C; g.ldc = y.C;
     g.mode = A_TCONV3; g.Cin = x.C; g.HW = x.H * x.W; g.F = F;
     g.bias = (const float*)w.b.p; g.res = res; g.ldr = y.C;
     g.epi = EPI_BIAS | (res ? EPI_RES : 0);
-    ok(op_gemm(ctx, g));
+    gemm_to(g, &y, stats);
   }
   // Attention(heads = 1, dim_head = C = 512, residual_connection, GroupNorm eps 1e-6), per frame.  One head of width 512 does not
   // fit the d = 64 flash kernel (the output tile alone would be 512 accumulators per lane), so the logits go through HBM -- but
@@ -146,7 +151,7 @@ struct VRun : Runner {
       }
     }
     Act y = make(C, x.H, x.W);
-    gemm(o.p(), C, rows(x), a.out, y.p(), C, x.p(), C);
+    gemm(o.p(), C, rows(x), a.out, y.p(), C, x.p(), C, 0, nullptr, out_stats ? &y : nullptr);
     return y;
   }
 };
@@ -222,13 +227,14 @@ int vae_encode(Ctx* ctx, const float* x, float* moments, int n, int H, int W) {
     if (!cols.p) return ctx->fail("out of device memory");
     if (op_stem_im2col(ctx, x + (size_t)i * cfg.in_ch * H * W, cols.p, cfg.in_ch, 1, H, W, true)) return 1;
     Act a = r.make(cfg.block_out[0], H, W);
-    r.gemm(cols.p, 64, H * W, M.e_conv_in, a.p(), a.C);
+    r.gemm(cols.p, 64, H * W, M.e_conv_in, a.p(), a.C, nullptr, 0, 0, nullptr, &a);   // + partials for the first resnet's norm1
     cols.reset();
     for (int b = 0; b < cfg.n_blocks; ++b) {
-      for (const Res2DW& rs : M.e_res[b]) a = r.res2d(rs, std::move(a));
+      for (size_t j = 0; j < M.e_res[b].size(); ++j)   // the last resnet of a level feeds the Downsample conv, not a GroupNorm
+        a = r.res2d(M.e_res[b][j], std::move(a), j + 1 < M.e_res[b].size() || b == cfg.n_blocks - 1);
       if (b != cfg.n_blocks - 1) {   // Downsample2D(padding=0): pad (0,1,0,1) then conv stride 2
         Act d = r.make(a.C, a.H / 2, a.W / 2);
-        r.conv3x3(a, M.e_down[b], d, A_CONV3X3, 2, 0, 0, nullptr);
+        r.conv3x3(a, M.e_down[b], d, A_CONV3X3, 2, 0, 0, nullptr, nullptr, 0, nullptr, 0, 1, true);
         a = std::move(d);
       }
       if (r.rc) return r.rc;
@@ -255,13 +261,17 @@ int vae_decode(Ctx* ctx, const float* z, float* out, int n, int h, int w) {
   if (!cols.p) return ctx->fail("out of device memory");
   if (op_stem_im2col(ctx, z, cols.p, cfg.latent, n, h, w, true)) return 1;
   Act a = r.make(cfg.block_out[cfg.n_blocks - 1], h, w);
-  r.gemm(cols.p, 64, n * h * w, M.d_conv_in, a.p(), a.C);
+  r.gemm(cols.p, 64, n * h * w, M.d_conv_in, a.p(), a.C, nullptr, 0, 0, nullptr, &a);
   cols.reset();
   a = r.stres(M.d_mid0, std::move(a));
   a = r.attn(M.d_attn, std::move(a));
   a = r.stres(M.d_mid1, std::move(a));
   for (int b = 0; b < cfg.n_blocks; ++b) {
-    for (const STResW& s : M.d_res[b]) a = r.stres(s, std::move(a));
+    for (size_t j = 0; j < M.d_res[b].size(); ++j) {   // the last block of a level feeds the Upsample conv, not a GroupNorm
+      r.out_stats = j + 1 < M.d_res[b].size() || b == cfg.n_blocks - 1;
+      a = r.stres(M.d_res[b][j], std::move(a));
+    }
+    r.out_stats = true;
     if (b != cfg.n_blocks - 1) {     // Upsample2D: nearest x2 + conv 3x3
       Act u = r.make(M.d_up[b].N, 2 * a.H, 2 * a.W);
       r.conv3x3(a, M.d_up[b], u, A_CONV3X3_UP, 1, 1, 1, nullptr, nullptr, 0, nullptr, 0, /*up_crop=*/0);

@@ -718,6 +718,11 @@ GN_EPI_CASES = [   # mode, tile, (frames, H, W), Cin, Cout, residual
     ("tconv", 2, (5, 7, 9), 320, 320, True),       # TemporalConvBlock_v2 conv4 + identity
     ("tconv", 3, (4, 6, 8), 64, 64, False),
     ("plain", 3, (4, 64, 50), 64, 64, True),       # 12 800 rows: the whole-chunk finalize is split into parts along the slots (two-stage reduction)
+    # round 6: the power-of-two tiles that run the VAE's 128 / 256 / 512-wide layers (vae.cpp)
+    ("conv", 4, (2, 11, 9), 64, 128, True),        # 256 x 128 tile: ResnetBlock2D conv2 + shortcut at the full-resolution levels
+    ("conv", 1, (2, 11, 9), 64, 256, False),       # 256 x 256 tile
+    ("tconv", 1, (3, 10, 8), 128, 512, True),      # TemporalResnetBlock conv2 + spatial branch
+    ("plain", 4, (3, 11, 9), 64, 128, False),      # conv_in as an im2col GEMM (K = 64)
 ]
 
 
@@ -767,7 +772,7 @@ def test_group_norm_statistics_in_the_producer_epilogue(ctx, dtype, mode, tile, 
         assert_close(y, ref, dtype, what=f"gn from partials rps={rps}")
         assert (y.float() - y0.float()).abs().max().item() <= (2e-2 if dtype == torch.bfloat16 else 4e-3) * (1 + ref.abs().max().item())
     # a tile without the flavour: the output is still computed, no partials
-    out4, part4 = ctx.gemm(a, w, bias=b, res=res, force_tile=4 if mode == "plain" else 1, gn_partial=True, **kw)
+    out4, part4 = ctx.gemm(a, w, bias=b, res=res, force_tile=9, gn_partial=True, **kw)
     assert part4 is None and out4.shape == out.shape
 
 

@@ -42,11 +42,18 @@ def test_small_vae_encode_decode(backend, dtype, request):
     g = torch.Generator().manual_seed(1)
     H, W = (16, 32) if backend == "emu" else (40, 64)   # latent H*W must be a multiple of 8 (always true for legal UNet sizes)
     x = torch.randn(2, 3, H, W, generator=g).clamp(-1, 1)
+    n0 = vae.ctx.lib.gn_fused_count(vae.ctx.h)
     mom = vae.encode(x.to(dev)).latent_dist.parameters
     ref = VO.encode_moments(sd, cfg, x)
     assert rel_rms(mom, ref) < REL[dtype], rel_rms(mom, ref)
+    # round 6: every GroupNorm of the encoder finalizes from the statistics its producer's epilogue wrote (vae.cpp; 3 levels: 8 resnets x 2
+    # norms + the attention's norm + conv_norm_out = 18 per frame, 2 frames)
+    n1 = vae.ctx.lib.gn_fused_count(vae.ctx.h)
+    assert n1 - n0 == 2 * 18, n1 - n0
     z = torch.randn(3, 4, H // cfg.downsample, W // cfg.downsample, generator=g)
     out = vae.decode(z.to(dev), num_frames=3).sample
+    # ... and of the decoder, except the two norms behind an Upsample conv (the nearest-x2 gather has no statistics flavour): 11 blocks x 4 + 2 - 2
+    assert vae.ctx.lib.gn_fused_count(vae.ctx.h) - n1 == 11 * 4 + 2 - 2, vae.ctx.lib.gn_fused_count(vae.ctx.h) - n1
     refd = VO.decode(sd, cfg, z, 3)
     assert out.shape == refd.shape
     assert rel_rms(out, refd) < REL[dtype], rel_rms(out, refd)

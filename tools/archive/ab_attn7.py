@@ -3,7 +3,7 @@
 errors against fp32 softmax(QK^T/8)V on the smaller levels.   python tools/ab_attn7.py [f16|bf16] [9,40,41] [levels: L0,L1,L2]"""
 import os, sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from star_amd import lib as L
 dt = {"f16": torch.float16, "bf16": torch.bfloat16}[sys.argv[1] if len(sys.argv) > 1 else "f16"]
 variants = [int(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["9", "40", "41"])]

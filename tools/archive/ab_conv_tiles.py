@@ -2,7 +2,7 @@
 choice (tile 0); interleaved rounds, bit-equality asserted.   python tools/ab_conv_tiles.py 0,17"""
 import os, sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from star_amd import lib as L
 tiles = [int(g) for g in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["0", "17"])]
 dt = torch.float16

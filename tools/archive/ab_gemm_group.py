@@ -2,7 +2,7 @@
 library, interleaved rounds.   python tools/ab_gemm_group.py [groups: 0,4,8,16]"""
 import os, sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from star_amd import lib as L
 groups = [int(g) for g in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["0", "4", "8", "16"])]
 dt = torch.float16

@@ -5,7 +5,7 @@
    python tools/ab_gemm_r04.py [plain|conv]"""
 import os, sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from star_amd import lib as L
 dt = torch.float16
 ctx = L.Context(0, dt)

@@ -1,6 +1,6 @@
 """Run one attention variant at the L0 shape in a loop for N seconds (for power / clock sampling with rocm-smi alongside)."""
 import os, sys, time, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from star_amd import lib as L
 variant, secs = int(sys.argv[1]), float(sys.argv[2])
 fill = sys.argv[3] if len(sys.argv) > 3 else "randn"

@@ -1,7 +1,7 @@
 """Experiment: why are the K=320 GEMMs 3x slower inside the forward than in the micro-benchmark?"""
 import os, sys, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from star_amd import lib as L
 dt = torch.float16
 ctx = L.Context(0, dt)

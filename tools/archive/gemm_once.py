@@ -1,6 +1,6 @@
 """Launch a few GEMMs of given shape / tile (for rocprofv3 --pmc passes).  usage: gemm_once.py M N K tile[,tile...] [iters]"""
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from star_amd import lib as L
 M, N, K = (int(x) for x in sys.argv[1:4])
 tiles = [int(t) for t in sys.argv[4].split(",")]

@@ -1,7 +1,7 @@
 """three launches of one GEMM variant (product library force_tile id, or "vendor" = torch.matmul) for rocprofv3 --pmc passes
    usage: gemm_pmc_once.py M N K tile|vendor"""
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from star_amd import lib as L
 M, N, K = (int(x) for x in sys.argv[1:4])
 dt = torch.float16

@@ -41,5 +41,29 @@ SPEC
       timeout 300 ./tools/cbench/cbench $BL f16 tools/cbench/r06_cfg_batch.txt 6 > gpurun_out/r06_cbench_cfg_batch.txt 2>&1
       cut -c1-100 gpurun_out/r06_cbench_cfg_batch.txt
       timeout 900 python -m pytest tests/test_kernels.py -m gpu -x -q -k "tail_split or frame_interleaved or flash_attention_self or producer_epilogue" 2>&1 | tail -5 > gpurun_out/r06_pytest_new1.txt
-      cat gpurun_out/r06_pytest_new1.txt ;;
+      cat gpurun_out/r06_pytest_new1.txt
+      # (e) the VAE with / without GroupNorm statistics in the producers' epilogues, same box
+      ( timeout 300 python tools/vae_time.py 6; STAR_NO_GNEPI=1 timeout 300 python tools/vae_time.py 6 ) 2>&1 | grep -v amdgpu.ids > gpurun_out/r06_vae_gnepi_ab.txt
+      cat gpurun_out/r06_vae_gnepi_ab.txt
+      timeout 600 python -m pytest tests/test_vae.py tests/test_parity_cfg4.py -m gpu -x -q -s 2>&1 | grep -E "dB|passed|failed|rror" | tail -8 > gpurun_out/r06_pytest_new2.txt
+      cat gpurun_out/r06_pytest_new2.txt ;;
+  4)  # the composed FF-out / proj_out GEMM: UNet tests, the forward table both ways on ONE box, the cfg2-geometry parity lines
+      ( timeout 1200 python -m pytest tests/test_unet.py tests/test_kernels.py -m gpu -x -q 2>&1 | tail -4 ) > gpurun_out/r06_pytest_unet_ffpo.txt 2>&1
+      cat gpurun_out/r06_pytest_unet_ffpo.txt
+      ( timeout 400 python tools/profile_forward.py 2>&1 | grep -v amdgpu.ids ) > gpurun_out/r06_forward_detail_f16_ffpo.txt 2>&1
+      ( STAR_NO_FFPO=1 timeout 400 python tools/profile_forward.py 2>&1 | grep -v amdgpu.ids ) > gpurun_out/r06_forward_detail_f16_noffpo.txt 2>&1
+      for f in ffpo noffpo; do echo "== $f"; head -12 gpurun_out/r06_forward_detail_f16_$f.txt | cut -c1-110; done
+      ( timeout 900 python -m pytest tests/test_parity_cfg2.py tests/test_parity_cfg4.py -m gpu -q -x -s 2>&1 | grep -v amdgpu.ids | grep -E "dB|passed|failed|rror" ) > gpurun_out/r06_pytest_parity_ffpo.txt 2>&1
+      cat gpurun_out/r06_pytest_parity_ffpo.txt ;;
+  3)  # temporal conv: K order x frame-interleaved walk (the STAR_TCONV_KORDER switch lived only for this measurement: it was removed with
+      # the experiment -- +2.2 % at level 0, -2 % at levels 2-3 -- see gemm.h stage_post and DESIGN.md section 8) (+ the FETCH_SIZE of the level-0 launch both ways)
+      for o in 0 1; do echo "== STAR_TCONV_KORDER=$o"; STAR_TCONV_KORDER=$o timeout 120 ./tools/cbench/cbench $BL f16 tools/cbench/r06_tconv_korder.txt 8 | grep -v differ | cut -c1-120; done > gpurun_out/r06_cbench_tconv_korder.txt 2>&1
+      cat gpurun_out/r06_cbench_tconv_korder.txt
+      cd /tmp && export TMPDIR=/tmp
+      printf 'tconv 32 26352 320 0\ntconv 32 6696 640 0\n' > /tmp/tc.txt
+      for o in 0 1; do
+        STAR_TCONV_KORDER=$o timeout 60 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/r06_pmc_tconv_k$o -- $R/tools/cbench/cbench $BL f16 /tmp/tc.txt 1 > /dev/null 2>&1
+        echo "== STAR_TCONV_KORDER=$o"; python $R/tools/pmc_db_summary.py $R/gpurun_out/r06_pmc_tconv_k$o | grep -v "^==" | cut -c60-200
+      done > $R/gpurun_out/r06_pmc_tconv_korder.txt 2>&1
+      cat $R/gpurun_out/r06_pmc_tconv_korder.txt; rm -rf $R/gpurun_out/r06_pmc_tconv_k0 $R/gpurun_out/r06_pmc_tconv_k1 ;;
 esac
