@@ -47,6 +47,26 @@ SPEC
       cat gpurun_out/r06_vae_gnepi_ab.txt
       timeout 600 python -m pytest tests/test_vae.py tests/test_parity_cfg4.py -m gpu -x -q -s 2>&1 | grep -E "dB|passed|failed|rror" | tail -8 > gpurun_out/r06_pytest_new2.txt
       cat gpurun_out/r06_pytest_new2.txt ;;
+  7)  # closing evidence (one box): the whole GPU suite with its parity lines, smoke, the forward table, the bench line (per-family table from
+      # the warm-up clip -> roofline.families, power sampled live, operand sweep + live skeleton ceiling, CPU baseline), the same command under
+      # rocprofv3 --kernel-trace --stats, then the other configurations
+      O=gpurun_out/r06f; mkdir -p $O
+      ( time timeout 1800 python -m pytest tests -m gpu -q -x -s 2>&1 | grep -v amdgpu.ids | grep -E "dB|rel rms|relative rms|passed|failed|error|skipped|real" ) > $O/pytest_gpu_final.txt 2>&1
+      tail -5 $O/pytest_gpu_final.txt
+      timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee $O/smoke.txt
+      ( timeout 400 python tools/profile_forward.py 2>&1 | grep -v amdgpu.ids ) > $O/forward_detail_f16_final.txt 2>&1; head -2 $O/forward_detail_f16_final.txt
+      timeout 1200 python bench.py --steps 1 --warmup 1 > $O/bench_final_f16_n1.json 2> $O/bench.err
+      head -c 300 $O/bench_final_f16_n1.json; echo
+      ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_bench &&
+        timeout 700 rocprofv3 --kernel-trace --stats -d /tmp/prof_bench -o b --output-format csv -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-operand-sweep > $R/$O/bench_final_rocprof_f16_n1.json 2> $R/$O/rocprof.err;
+        f=$(find /tmp/prof_bench -name "*kernel_stats.csv" | head -1); cp "$f" $R/$O/bench_final_kernel_stats.csv 2>/dev/null )
+      head -4 $O/bench_final_kernel_stats.csv; head -c 200 $O/bench_final_rocprof_f16_n1.json; echo
+      timeout 400 python bench.py --config cfg3 --steps 1 --warmup 0 --no-cpu-baseline --no-operand-sweep > $O/bench_cfg3_fast_f16_n1.json 2>> $O/bench.err; head -c 200 $O/bench_cfg3_fast_f16_n1.json; echo
+      timeout 400 python bench.py --dtype bf16 --steps 1 --warmup 0 --no-cpu-baseline --no-operand-sweep > $O/bench_bf16_n1.json 2>> $O/bench.err; head -c 200 $O/bench_bf16_n1.json; echo
+      timeout 1100 python bench.py --config cfg4 --steps 1 --warmup 0 --no-cpu-baseline --no-operand-sweep > $O/bench_cfg4_50eval_f16_n1.json 2>> $O/bench.err; head -c 200 $O/bench_cfg4_50eval_f16_n1.json; echo ;;
+  5)  # two forwards on two streams at once against one after the other (upper bound of a two-stream CFG pair)
+      ( timeout 600 python tools/concurrent_forward.py 3 2>&1 | grep -v amdgpu.ids | tail -3 ) > gpurun_out/r06_concurrent_forward.txt 2>&1
+      cat gpurun_out/r06_concurrent_forward.txt ;;
   4)  # the composed FF-out / proj_out GEMM: UNet tests, the forward table both ways on ONE box, the cfg2-geometry parity lines
       ( timeout 1200 python -m pytest tests/test_unet.py tests/test_kernels.py -m gpu -x -q 2>&1 | tail -4 ) > gpurun_out/r06_pytest_unet_ffpo.txt 2>&1
       cat gpurun_out/r06_pytest_unet_ffpo.txt
