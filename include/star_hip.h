@@ -80,7 +80,8 @@ typedef struct star_gemm_desc {
                                         for n compute units instead of the device's (the launcher gives a poorly filled last round of big
                                         tiles to a second launch of 128 x 128 tiles); 18 the persistent one-wave-per-SIMD tile (gemm_p.h:
                                         plain A, 16-bit output, bias / residual / STAR_EPI_ROWAFF), 2000 + n the same on n resident workgroups;
-                                        anything else: bench build only */
+                                        17 / 19 the scheduled one-wave-per-SIMD tiles 256x256 / 256x320 (gemm.h SCHED: plain, 3x3 and temporal
+                                        convs, bias / residual 16-bit epilogues); anything else: bench build only */
   const float* rowab;                /* STAR_EPI_ROWAFF (a LayerNorm folded into this projection, unet_v2v.py:448-450 + the Linear behind it): */
   const float* colsum;               /*   out = a_m * acc + b_m * colsum[n] + bias[n], (a_m, b_m) = rowab[m] fp32 pairs, colsum fp32 [N]; else null */
 } star_gemm_desc;

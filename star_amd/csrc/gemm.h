@@ -335,6 +335,14 @@ gemm_kernel(const GemmParams p) {
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // the scheduled 4 x 5 tile keeps its fifth block column in architectural registers and multiplies into it with inline-asm MFMAs
+  // (prim.h: mfma32_vform), which the compiler's hazard recognizer cannot see: left alone it re-materialises these zeros with v_mov
+  // right in front of the first MFMA that reads them -- a VALU write -> MFMA srcC read with no wait states, and the first register
+  // arrived late on hardware (the emulator cannot show it).  Pinned here, far from the loop, the zeros are ordinary live values.
+  if constexpr (SCHED != 0 && TN == 5) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) STAR_VGPR_PIN(acc[i][TN - 1]);
+  }
 
   // fragment read offsets (bytes within a stage); row R, chunk c -> R*128 + ((c ^ ((R>>1)&7))<<4)
   const int frow = lane & 31, fhalf = lane >> 5;
@@ -503,7 +511,11 @@ gemm_kernel(const GemmParams p) {
   // phase 3, the W pieces in the last 8 gaps of the next tile's phase 0 -- 1.5 to 2 tile times before they are waited for.
   // The pieces are whole 128-byte lines (8 rows per wave-instruction), as in the 8-wave loop: the 32-deep ring slots of the
   // pipelined loop above ask the L2 for every line twice (TCP_TCC_READ_REQ 134 M against 67 M at 8192^3, profiles/r03_gemm_sched_pmc.txt).
-  static_assert(PIPE == 0 && TM == 4 && TN == 4 && NT == 256 && NA == 8 && NW == 8 && !STAGGER, "the scheduled loop is built for 4 waves x (128 x 128)");
+  // Round 6: the same placement for any TM x TN with TM + TN reads <= the even gaps and NA / NW copies <= the odd gaps of a phase: 4 x 5
+  // blocks = 4 waves x (128 x 160), the 256 x 320 tile with one wave per SIMD (320 accumulators, 9 fragment reads per 20 MFMAs).
+  constexpr int NM = TM * TN;                       // MFMAs per phase
+  static_assert(PIPE == 0 && NT == 256 && !STAGGER && TM == 4 && (TN == 4 || TN == 5), "the scheduled loop is built for 4 waves, 128 rows per wave");
+  static_assert(2 * (TM + TN) <= NM + 1 && 2 * NA <= NM && 2 * NW <= NM, "a phase's reads go into its even gaps, its copies into the odd ones");
   const char* afb[4];
   const char* wfb[4];
 #pragma unroll
@@ -512,18 +524,24 @@ gemm_kernel(const GemmParams p) {
     afb[ks] = opaque(smem + (wm * WTM + frow) * 128 + sw);
     wfb[ks] = opaque(smem + 2 * A_STAGE + (wn * WTN + frow) * 128 + sw);
   }
-  vec<T, 8> fa[2][4], fw[2][4];
-  auto frag_read = [&](auto cks, int sa, int swo, auto ci, auto cb) STAR_ALWAYS_INLINE {   // read #ci (0-3: A blocks, 4-7: W blocks) of 16-k step cks into buffer cb
+  vec<T, 8> fa[2][TM], fw[2][TN];
+  auto frag_read = [&](auto cks, int sa, int swo, auto ci, auto cb) STAR_ALWAYS_INLINE {   // read #ci (0..TM-1: A blocks, TM..: W blocks) of 16-k step cks into buffer cb
     constexpr int KS = decltype(cks)::value, I = decltype(ci)::value, Bf = decltype(cb)::value;
-    if constexpr (I < 4) fa[Bf][I] = *reinterpret_cast<const vec<T, 8>*>(afb[KS] + sa + I * 4096);
-    else fw[Bf][I - 4] = *reinterpret_cast<const vec<T, 8>*>(wfb[KS] + swo + (I - 4) * 4096);
+    if constexpr (I < TM) fa[Bf][I] = *reinterpret_cast<const vec<T, 8>*>(afb[KS] + sa + I * 4096);
+    else fw[Bf][I - TM] = *reinterpret_cast<const vec<T, 8>*>(wfb[KS] + swo + (I - TM) * 4096);
   };
   auto phase = [&](auto cb, auto body) STAR_ALWAYS_INLINE {
     constexpr int Bf = decltype(cb)::value;
-    static_for<16>([&](auto q) STAR_ALWAYS_INLINE {
+    static_for<NM>([&](auto q) STAR_ALWAYS_INLINE {
       constexpr int Q = decltype(q)::value;
-      constexpr int i = Q >> 2, j = (i & 1) ? 3 - (Q & 3) : (Q & 3);   // serpentine: consecutive MFMAs share one operand
-      acc[i][j] = mfma32<T>(fw[Bf][j], fa[Bf][i], acc[i][j]);
+      constexpr int i = Q / TN, j = (i & 1) ? TN - 1 - (Q % TN) : (Q % TN);   // serpentine: consecutive MFMAs share one operand
+      // 4 x 5 blocks are 320 accumulators: the first four block columns live in the 256 accumulation registers, the fifth in 64
+      // architectural ones -- said explicitly, or hipcc rotates accumulators through v_accvgpr_read / _write (672 per K tile) and scratch
+      if constexpr (TN == 5 && j == 4) mfma32_vform<T>(fw[Bf][j], fa[Bf][i], acc[i][j]);
+      else {
+        acc[i][j] = mfma32<T>(fw[Bf][j], fa[Bf][i], acc[i][j]);
+        if constexpr (TN == 5) STAR_AGPR_PIN(acc[i][j]);
+      }
       body(q);
       STAR_SCHED_FENCE();
     });
@@ -533,17 +551,17 @@ gemm_kernel(const GemmParams p) {
   stage(0, 0);
   if (nk > 1) { stage(1, 1); STAR_WAIT_VMCNT_N(NA + NW); } else { STAR_WAIT_VMCNT(0); }
   barrier_keep_dma();
-  static_for<8>([&](auto c) STAR_ALWAYS_INLINE { frag_read(B0{}, 0, 0, c, B0{}); });
+  static_for<TM + TN>([&](auto c) STAR_ALWAYS_INLINE { frag_read(B0{}, 0, 0, c, B0{}); });
   STAR_SCHED_FENCE();
   int sa = 0, swo = 0;                    // byte offsets of the stage tile kt is read from
   // STEADY: both copy groups are due; otherwise (first tile, last two) they are runtime-conditional
   // memory operations of a phase: the fragment reads in the even MFMA gaps, the copies (phases 3 and 0) in the odd ones.  Read
-  // order W0 A0 W1 W2 W3 A1 A2 A3 = the order the next phase's MFMAs first need them.
+  // order W0 A0 W1 .. W(TN-1) A1 .. A(TM-1) = the order the next phase's MFMAs first need them.
   auto rd = [&](auto cks, auto q, auto cb) STAR_ALWAYS_INLINE {
     constexpr int Q = decltype(q)::value;
-    if constexpr ((Q & 1) == 0) {
+    if constexpr ((Q & 1) == 0 && (Q >> 1) < TM + TN) {
       constexpr int R = Q >> 1;
-      constexpr int I = R == 0 ? 4 : R == 1 ? 0 : R == 2 ? 5 : R == 3 ? 6 : R == 4 ? 7 : R - 4;
+      constexpr int I = R == 0 ? TM : R == 1 ? 0 : R <= TN ? TM + R - 1 : R - TN;
       frag_read(cks, sa, swo, std::integral_constant<int, I>{}, cb);
     }
   };
@@ -554,22 +572,22 @@ gemm_kernel(const GemmParams p) {
     phase(B0{}, [&](auto q) STAR_ALWAYS_INLINE {
       constexpr int Q = decltype(q)::value;
       rd(B1{}, q, B1{});
-      if constexpr ((Q & 1) == 1 && ABL != 8 && ABL != 11) { if (iw) stage_piece(ABL == 9 ? 0 : kt + 1, buf ^ 1, std::integral_constant<int, (ABL == 9 ? NA : NA + (Q >> 1))>{}); }   // W pieces of tile kt+1
-      if constexpr (Q == 15 && ABL != 8) { if (iw) stage_post(); }
+      if constexpr ((Q & 1) == 1 && (Q >> 1) < NW && ABL != 8 && ABL != 11) { if (iw) stage_piece(ABL == 9 ? 0 : kt + 1, buf ^ 1, std::integral_constant<int, (ABL == 9 ? NA : NA + (Q >> 1))>{}); }   // W pieces of tile kt+1
+      if constexpr (Q == NM - 1 && ABL != 8) { if (iw) stage_post(); }
     });
     phase(B1{}, [&](auto q) STAR_ALWAYS_INLINE { rd(std::integral_constant<int, 2>{}, q, B0{}); });
     phase(B0{}, [&](auto q) STAR_ALWAYS_INLINE {
       constexpr int Q = decltype(q)::value;
       rd(std::integral_constant<int, 3>{}, q, B1{});
-      if constexpr (Q == 14 && ABL != 10) { STAR_WAIT_VMCNT(0); }
-      if constexpr (Q == 15) barrier_keep_dma();
+      if constexpr (Q == NM - 2 && ABL != 10) { STAR_WAIT_VMCNT(0); }
+      if constexpr (Q == NM - 1) barrier_keep_dma();
     });
     sa ^= A_STAGE; swo ^= W_STAGE;
     phase(B1{}, [&](auto q) STAR_ALWAYS_INLINE {
       constexpr int Q = decltype(q)::value;
       if constexpr (Q == 0 && ABL != 8) { if (ia) stage_pre(); }
       rd(B0{}, q, B0{});
-      if constexpr ((Q & 1) == 1 && ABL != 8) { if (ia) stage_piece(ABL == 9 ? 0 : kt + 2, buf, std::integral_constant<int, (ABL == 9 ? 0 : (Q >> 1))>{}); }   // A pieces of tile kt+2
+      if constexpr ((Q & 1) == 1 && (Q >> 1) < NA && ABL != 8) { if (ia) stage_piece(ABL == 9 ? 0 : kt + 2, buf, std::integral_constant<int, (ABL == 9 ? 0 : (Q >> 1))>{}); }   // A pieces of tile kt+2
     });
   };
   {

@@ -58,8 +58,10 @@ static int launch_gemm_f(Ctx* ctx, const GemmArgs& a) {
     if constexpr (GNS && !F32OUT) {
       // (the scheduled one-wave-per-SIMD tile has the flavour without a residual only: with the residual's registers beside its 256
       // accumulators the bf16 instantiation spilled one register; launch_gemm drops the request there)
-      if constexpr (SCHED != 0) { if (res) return ctx->fail("gemm: the scheduled tile has no GroupNorm-statistics flavour with a residual"); }
-#define STAR_GEMM_GO_GN(MODE) do { if constexpr (SCHED == 0) { if (res) STAR_GEMM_GO(MODE, 17); else STAR_GEMM_GO(MODE, 16); } else STAR_GEMM_GO(MODE, 16); } while (0)
+      // (round 6: the 256 x 320 scheduled tile, BN == 320, is tried WITH the residual flavour: its fifth block column is in architectural registers anyway)
+      constexpr bool RES_GN = SCHED == 0 || BN == 320;
+      if constexpr (!RES_GN) { if (res) return ctx->fail("gemm: the scheduled tile has no GroupNorm-statistics flavour with a residual"); }
+#define STAR_GEMM_GO_GN(MODE) do { if constexpr (RES_GN) { if (res) STAR_GEMM_GO(MODE, 17); else STAR_GEMM_GO(MODE, 16); } else STAR_GEMM_GO(MODE, 16); } while (0)
       switch (a.mode) {
         case A_PLAIN: STAR_GEMM_GO_GN(A_PLAIN); break;
         case A_CONV3X3: STAR_GEMM_GO_GN(A_CONV3X3); break;
@@ -111,10 +113,12 @@ int launch_gemm_persist(Ctx* ctx, const GemmArgs& a);   // gemm_p.cpp
 bool gemm_persist_covers(const GemmArgs& a);
 
 #ifdef STAR_BENCH_VARIANTS
+static bool no_sched320_env() { return std::getenv("STAR_NO_SCHED320") != nullptr; }
 static bool no_sched_env() { return std::getenv("STAR_NO_SCHED") != nullptr; }
 static bool no_persist_env() { return std::getenv("STAR_NO_PERSIST") != nullptr; }
 #else
 static bool no_persist_env() { static const bool v = std::getenv("STAR_NO_PERSIST") != nullptr; return v; }   // read once (A/B switch)
+static bool no_sched320_env() { static const bool v = std::getenv("STAR_NO_SCHED320") != nullptr; return v; }   // read once (A/B switch)
 static bool no_sched_env() { static const bool v = std::getenv("STAR_NO_SCHED") != nullptr; return v; }   // read once (A/B switch)
 #endif
 
@@ -141,19 +145,29 @@ static int launch_gemm(Ctx* ctx, const GemmArgs& a) {
     // to the 256 x 320 tile (N = 640 would waste a sixth of three 256-column tiles)
     // ... and whose tiles fill the resident workgroups' rounds to >= 88 % (the persistent walk is static: 1080 tiles on 256 CUs are 5
     // rounds for some workgroups; there the 256 x 320 tile + tail split measured ahead, profiles/r04_gemm_ab_v3_auto.txt)
-    // (round 6: a last column tile that is half empty is accepted where it wastes <= 1/15 of the tiles -- the level-1 q | k | v, N = 1920:
-    // +3.0 % over the 256 x 320 tile, bit-identical, profiles/r06_cbench_ffpo_tiles.txt.  Asking for the output's GroupNorm partials keeps a
-    // layer off this tile; the only such layer it could run, the level-2 composed FF-out / proj_out GEMM, is 3.6 % FASTER on the 256 x 320
-    // tile + tail split anyway: same file)
-    bool persist_ok = gemm_persist_covers(a) && a.K >= 512 && (a.N % 256 == 0 || (a.N % 256 == 128 && a.N >= 1792)) && a.N >= 1024 && !no_persist_env() &&
-                      !a.gn_partial && !a.ln_partial;
+    // (round 6, measured and dropped: accepting a half-empty last column tile -- the level-1 q | k | v, N = 1920 -- is +3.0 % in cbench
+    // (profiles/r06_cbench_ffpo_tiles.txt) and -8 % IN SITU (0.599 -> 0.647 ms, same box: profiles/r06_forward_detail_f16_ragged18.txt /
+    // _noragged18.txt): the in-situ figure decides.  Asking for the output's GroupNorm partials keeps a layer off this tile; the only such
+    // layer it could run, the level-2 composed FF-out / proj_out GEMM, is 3.6 % faster on the 256 x 320 tile + tail split anyway: ADVICE r05.)
+    bool persist_ok = gemm_persist_covers(a) && a.K >= 512 && a.N % 256 == 0 && a.N >= 1024 && !no_persist_env() && !a.gn_partial && !a.ln_partial;
     if (persist_ok) {
       const int cus = a.assume_cus > 0 ? a.assume_cus : (ctx->num_cus > 0 ? ctx->num_cus : 256);
-      const int64_t nt = (int64_t)((a.M + 255) / 256) * ((a.N + 255) / 256), rounds = (nt + cus - 1) / cus;
+      const int64_t nt = (int64_t)((a.M + 255) / 256) * (a.N / 256), rounds = (nt + cus - 1) / cus;
       persist_ok = nt >= 2 * (int64_t)cus && (double)nt >= 0.88 * (double)(rounds * cus);
     }
+    // round 6: the same scheduled loop on the 256 x 320 tile (4 waves x (128 x 160), 320 accumulators per wave: tile 19) for the long-K
+    // layers the 8-wave 256 x 320 tile ran: 9 fragment reads per 20 MFMAs instead of 7 per 10, bit-identical.  Decided IN SITU (whole
+    // forwards with / without on one box, profiles/r06_forward_detail_f16_tile19_*.txt / _notile19_*.txt): 3 x 3 convs -7 ... -9.5 % (K = 2880
+    // ... 23040; the level-0 conv2 with residual + statistics -1.4 %), temporal convs K = 1920 -3.8 %, K = 3840 at level 3 -7.4 % (K = 960:
+    // 0 in cbench, not taken), plain K = 6400 -2.4 % but K = 2560 +3.6 % (the 8-wave tile hides a short loop's prologue better: plain layers
+    // from K = 3200 only): -4.9 ms per forward.  STAR_NO_SCHED320=1: tile 2 (A/B switch, read once).
+    const bool sched320_ok = !geglu && a.N % 320 == 0 && !(a.M <= 4096 && a.N <= 1024) && !a.ln_partial &&
+                             !(a.epi & (EPI_OUT_F32 | EPI_ROWAFF | EPI_GELU_TANH | EPI_GEGLU)) &&
+                             ((a.mode == A_CONV3X3 && a.K >= 2880) || (a.mode == A_TCONV3 && a.K >= 1920) || (a.mode == A_PLAIN && a.K >= 3200)) &&
+                             !no_sched320_env();
     if (persist_ok) tile = 18;
     else if (sched_ok) tile = 17;
+    else if (sched320_ok) tile = 19;
     else if (a.M <= 4096 && a.N <= 1024) tile = 3;                     // small problems: more, smaller tiles
     else if (!geglu && a.N % 320 == 0) tile = 2;                        // 320 / 640 / 960 / 1280 / 1920-wide layers
     // (rounds 1-2 sent the short-K GEGLU layers to tile 9, two 4-wave workgroups per CU hiding each other's GELU epilogue;
@@ -177,7 +191,7 @@ static int launch_gemm(Ctx* ctx, const GemmArgs& a) {
   // GroupNorm statistics in the epilogue: the flavour exists for tiles 1-4 and 17 on plain / 3x3 / temporal-conv layers with the
   // bias (+ residual) 16-bit epilogue (round 6: + the power-of-two tiles 1 and 4, which run the VAE's 128 / 256 / 512-wide layers);
   // elsewhere the request is dropped (gn_done stays false: the consumer runs its own pass)
-  if (a.gn_partial && (!(tile == 1 || tile == 2 || tile == 3 || tile == 4 || tile == 17) || (tile == 17 && (a.epi & EPI_RES)) || !(a.mode == A_PLAIN || a.mode == A_CONV3X3 || a.mode == A_TCONV3) ||
+  if (a.gn_partial && (!(tile == 1 || tile == 2 || tile == 3 || tile == 4 || tile == 17 || tile == 19) || (tile == 17 && (a.epi & EPI_RES)) || !(a.mode == A_PLAIN || a.mode == A_CONV3X3 || a.mode == A_TCONV3) ||
                        (a.epi & (EPI_OUT_F32 | EPI_ROWAFF | EPI_GELU_TANH | EPI_GEGLU)) || (a.N & 7))) {
     GemmArgs b = a;
     b.gn_partial = nullptr;
@@ -188,9 +202,9 @@ static int launch_gemm(Ctx* ctx, const GemmArgs& a) {
   // their time with three quarters of the chip idle.  When the last round is poorly filled, the launch covers only the tile rows of
   // the FULL rounds and the remaining rows go to a second launch of 128 x 128 tiles (tile 3: two workgroups per CU, every mode and
   // epilogue flavour, same k order per output -- bit-identical).  Decided by a cost model in units of one big tile's time.
-  if (!a.force_tile && a.m_off == 0 && a.m_end == 0 && !a.ln_partial && (tile == 1 || tile == 2 || tile == 17)) {   // (row statistics: the remainder tile would cut the rows into a different number of parts)   // (the persistent tile 18 is only chosen where its rounds are full)
+  if (!a.force_tile && a.m_off == 0 && a.m_end == 0 && !a.ln_partial && (tile == 1 || tile == 2 || tile == 17 || tile == 19)) {   // (row statistics: the remainder tile would cut the rows into a different number of parts)   // (the persistent tile 18 is only chosen where its rounds are full)
     const int cus = a.assume_cus > 0 ? a.assume_cus : (ctx->num_cus > 0 ? ctx->num_cus : 256);
-    const int bm = 256, bn = tile == 2 ? 320 : 256;
+    const int bm = 256, bn = (tile == 2 || tile == 19) ? 320 : 256;
     const long long tm = (a.M + bm - 1) / bm, tn = (a.N + bn - 1) / bn, nt = tm * tn;
     const long long full = nt / cus;                      // full rounds
     if (full >= 1 && nt % cus != 0) {
@@ -224,6 +238,10 @@ static int launch_gemm(Ctx* ctx, const GemmArgs& a) {
     case 17:
       if (a.epi & (EPI_OUT_F32 | EPI_ROWAFF | EPI_GELU_TANH | EPI_GEGLU)) return ctx->fail("gemm: tile 17 has the plain and residual 16-bit epilogues only");
       return launch_gemm_f<T, 256, 256, 2, 2, 1, false, false, 0, false, 1, 0, true>(ctx, a);
+    // round 6: the scheduled loop on the 256 x 320 tile: 4 waves x (128 x 160), 320 accumulators per wave, 9 fragment reads per 20 MFMAs
+    case 19:
+      if (a.epi & (EPI_OUT_F32 | EPI_ROWAFF | EPI_GELU_TANH | EPI_GEGLU)) return ctx->fail("gemm: tile 19 has the plain and residual 16-bit epilogues only");
+      return launch_gemm_f<T, 256, 320, 2, 2, 1, false, false, 0, false, 1, 0, true>(ctx, a);
     case 18: return launch_gemm_persist(ctx, a);   // persistent one-wave-per-SIMD tile with a wave-private epilogue (gemm_p.h)
 #ifdef STAR_BENCH_VARIANTS   // round-6 A/Bs of tile 18's walk and store policy (bit-identical): 60 = PLAIN stores, the round-5 kernel (the product stores non-temporally since round 6; + 66: plain stores on column strips of 8);
     // 61 / 62 / 63 = row groups of 1 / 4 / 16 (product: 8 where a tile row is >= 12 tiles wide); 64 / 65 / 67 = column strips of 8 / 4 / 16

@@ -1,4 +1,5 @@
 // gemm_p.cpp -- launcher of gemm_persist_kernel (gemm_p.h): the persistent one-wave-per-SIMD GEMM for plain-A layers ("tile 18").
+#include <cstdlib>
 #include "ops.h"
 #include "gemm_p.h"
 
@@ -32,7 +33,7 @@ static int launch_persist_t(Ctx* ctx, const GemmArgs& a) {
   constexpr size_t smem = 2 * (size_t)(256 + 256) * 128 + 4 * (size_t)4096 + 2 * (size_t)2048;
   const dim3 grid((unsigned)G), block(256);
 #ifdef STAR_BENCH_VARIANTS   // round-6 A/B reference (bit-identical): 60 = the round-5 kernel's plain output stores
-  if (a.force_tile == 60) {
+  if (a.force_tile == 60 || std::getenv("STAR_PERSIST_PLAIN")) {   // (the environment switch: in-situ A/B of a whole forward on the bench build)
     if ((a.epi & EPI_ROWAFF) && (a.epi & EPI_GEGLU)) STAR_LAUNCH((gemm_persist_kernel<T, 10, 0>), grid, block, smem, ctx->stream, p);
     else if (a.epi & EPI_GEGLU) STAR_LAUNCH((gemm_persist_kernel<T, 2, 0>), grid, block, smem, ctx->stream, p);
     else if (a.epi & EPI_ROWAFF) STAR_LAUNCH((gemm_persist_kernel<T, 8, 0>), grid, block, smem, ctx->stream, p);

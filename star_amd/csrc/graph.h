@@ -376,8 +376,10 @@ struct Runner {
     g.epi = (g.bias ? EPI_BIAS : 0) | (res ? EPI_RES : 0) | extra_epi;
     gemm_to(g, (out_override || ldc_override) ? nullptr : &y, stats && !out_override && !ldc_override);
   }
+  // y may be x itself (in place): its producer's partial statistics describe the un-normalised values and are dropped afterwards
   void gn(const Act& x, const NormW& n, Act& y, bool whole_chunk, float eps, bool silu) {
     const int rps = whole_chunk ? F * x.H * x.W : x.H * x.W;
+    struct Drop { Act& y; bool on; ~Drop() { if (on) y.gnp.reset(); } } drop_stale{y, x.p() == y.p()};
     if (x.gnp && x.gnp->p)   // the producer of x left its partial statistics: finalize from them, no statistics pass
       ok(op_group_norm_fused(ctx, x.p(), x.C, y.p(), y.C, (const float*)n.g.p, (const float*)n.b.p, rows(x), x.C, rps, eps, silu, x.gnp->as<float>()));
     else

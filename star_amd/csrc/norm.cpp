@@ -40,7 +40,8 @@ static int gn_t(Ctx* ctx, const void* x, int ldx, void* y, int ldy, const float*
   STAR_LAUNCH(gn_finalize_kernel, dim3((unsigned)((nstat * 32 + 3) / 4)), dim3(256), (size_t)0, ctx->stream, fp);
   if (ab_out) return 0;
   GnApplyParams ap{x, y, abp, ldx, ldy, C, rows_per_stat, slab, silu ? 1 : 0};
-  STAR_LAUNCH((gn_apply_kernel<T>), grid, dim3(nthreads), (size_t)0, ctx->stream, ap);
+  if (silu) STAR_LAUNCH((gn_apply_kernel<T, true>), grid, dim3(nthreads), (size_t)0, ctx->stream, ap);
+  else STAR_LAUNCH((gn_apply_kernel<T, false>), grid, dim3(nthreads), (size_t)0, ctx->stream, ap);
   return 0;
 }
 
@@ -74,7 +75,8 @@ static int gn_fused_t(Ctx* ctx, const void* x, int ldx, void* y, int ldy, const 
   while ((long long)((rows_per_stat + slab - 1) / slab) * nstat < 1024 && slab > 32) slab >>= 1;
   const int nslab = (rows_per_stat + slab - 1) / slab;
   GnApplyParams ap{x, y, abp, ldx, ldy, C, rows_per_stat, slab, silu ? 1 : 0};
-  STAR_LAUNCH((gn_apply_kernel<T>), dim3((unsigned)nslab, (unsigned)nstat), dim3((unsigned)(CC8 * RL)), (size_t)0, ctx->stream, ap);
+  if (silu) STAR_LAUNCH((gn_apply_kernel<T, true>), dim3((unsigned)nslab, (unsigned)nstat), dim3((unsigned)(CC8 * RL)), (size_t)0, ctx->stream, ap);
+  else STAR_LAUNCH((gn_apply_kernel<T, false>), dim3((unsigned)nslab, (unsigned)nstat), dim3((unsigned)(CC8 * RL)), (size_t)0, ctx->stream, ap);
   return 0;
 }
 

@@ -200,7 +200,10 @@ struct GnApplyParams {
 };
 // grid (slab, stat), CC8 x RL threads like gn_stats_kernel: a thread owns one 8-channel chunk, keeps its 16 affine
 // coefficients in registers and walks the rows of the slab (no index divisions, no coefficient re-loads in the loop)
-template <class T>
+// SILU: compile-time (round 6: the run-time flag cost one v_cndmask per element).  x and y may be the SAME tensor (in place: a thread
+// reads a 16-byte chunk and writes the same chunk; Fwd::res_block normalises the tensors nobody else reads in place -- an in-place
+// read-modify-write stream runs 6.1 TB/s on this part against 5.2 for a copy, profiles/r01_hbm_rw_probe.txt).
+template <class T, bool SILU>
 STAR_GLOBAL void gn_apply_kernel(const GnApplyParams p) {
   const int CC8 = p.C >> 3;
   const int t = threadIdx.x;
@@ -216,14 +219,14 @@ STAR_GLOBAL void gn_apply_kernel(const GnApplyParams p) {
               ab2 = *reinterpret_cast<const f32x4*>(ab + 8), ab3 = *reinterpret_cast<const f32x4*>(ab + 12);
   const float av[8] = {ab0[0], ab0[2], ab1[0], ab1[2], ab2[0], ab2[2], ab3[0], ab3[2]};
   const float bv[8] = {ab0[1], ab0[3], ab1[1], ab1[3], ab2[1], ab2[3], ab3[1], ab3[3]};
-  const T* __restrict__ xb = (const T*)p.x + ((size_t)stat * p.rows_per_stat) * p.ldx + cc * 8;
-  T* __restrict__ yb = (T*)p.y + ((size_t)stat * p.rows_per_stat) * p.ldy + cc * 8;
+  const T* xb = (const T*)p.x + ((size_t)stat * p.rows_per_stat) * p.ldx + cc * 8;
+  T* yb = (T*)p.y + ((size_t)stat * p.rows_per_stat) * p.ldy + cc * 8;
   auto one = [&](int r, const vec<T, 8>& v) {
     vec<T, 8> o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float f = to_f32<T>(v[e]) * av[e] + bv[e];
-      if (p.silu) f = silu_f(f);
+      if constexpr (SILU) f = silu_f(f);
       o[e] = from_f32<T>(f);
     }
     *reinterpret_cast<vec<T, 8>*>(yb + (size_t)r * p.ldy) = o;

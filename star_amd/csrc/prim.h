@@ -155,6 +155,19 @@ STAR_DEV f32x16 mfma32(vec<T, 8> a, vec<T, 8> b, f32x16 c) {
 #endif
 }
 
+// The same MFMA with its accumulator in ARCHITECTURAL registers (the "VGPR form").  hipcc selects one form per function (accumulation
+// registers here), so a tile with more than 256 accumulators -- gemm.h's 4 x 5 scheduled tile keeps 64 of its 320 in v-registers -- names
+// the form of those MFMAs itself; through the builtin the compiler copies the block into accumulation registers and back around every MFMA.
+template <class T>
+STAR_DEV void mfma32_vform(vec<T, 8> a, vec<T, 8> b, f32x16& c) {
+#ifdef STAR_HOSTEMU
+  c = mfma32<T>(a, b, c);
+#else
+  if constexpr (sizeof(T) == 2 && __is_same(T, bf16)) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+  else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+#endif
+}
+
 // D = A(32x8) * B(8x32) + C (the pre-CDNA4 half-depth form).  lane l: a[j] = A[l&31][4*(l>>5)+j], b[j] = B[4*(l>>5)+j][l&31]
 template <class T>
 STAR_DEV f32x16 mfma32_k8(vec<T, 4> a, vec<T, 4> b, f32x16 c) {
@@ -654,8 +667,10 @@ STAR_DEV float max8(vec<T, 8> v) {
 // read from AGPRs in place, and the architectural VGPRs stay free for what vector instructions touch (one-wave-per-SIMD kernels)
 #ifdef STAR_HOSTEMU
 #define STAR_AGPR_PIN(x)
+#define STAR_VGPR_PIN(x)
 #else
 #define STAR_AGPR_PIN(x) asm volatile("" : "+a"(x))
+#define STAR_VGPR_PIN(x) asm volatile("" : "+v"(x))   // ... in architectural registers (a 320-accumulator tile keeps 64 of them there)
 #endif
 
 // compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{})

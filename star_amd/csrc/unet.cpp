@@ -100,8 +100,11 @@ struct Fwd : Runner {
     Act h1 = make(r.cout, x.H, x.W);
     conv3x3(n1, r.conv1, h1, A_CONV3X3, 1, 1, 1, nullptr, bias1.as<float>(), 0, nullptr, 0, 1, true);   // + h1's GroupNorm partials (gn2)
     n1.drop();
-    Act n2 = make(r.cout, x.H, x.W);
-    gn(h1, r.gn2, n2, false, 1e-5f, true);
+    // out_layers.0 in place: nobody else reads h1 (STAR_NO_GN_INPLACE=1: a separate output tensor, the round-5 form; A/B switch, read once)
+    static const bool gn_inplace = std::getenv("STAR_NO_GN_INPLACE") == nullptr;
+    Act n2;
+    if (gn_inplace) { gn(h1, r.gn2, h1, false, 1e-5f, true); n2 = std::move(h1); }
+    else { n2 = make(r.cout, x.H, x.W); gn(h1, r.gn2, n2, false, 1e-5f, true); }
     h1.drop();
     Act skip;
     const void* sp = x.p();
@@ -116,9 +119,10 @@ struct Fwd : Runner {
     // temporal conv block: 4 x [GN(whole chunk) + SiLU + Conv3d(3,1,1)] + identity
     Act cur;  // null => h2
     for (int k = 0; k < 4; ++k) {
-      const Act& in = (k == 0) ? h2 : cur;
-      Act nn = make(r.cout, h2.H, h2.W);
-      gn(in, r.tgn[k], nn, true, 1e-5f, true);
+      // the first norm reads h2, which the block's identity adds back at the end; the other three normalise their input in place
+      Act nn;
+      if (k == 0 || !gn_inplace) { nn = make(r.cout, h2.H, h2.W); gn(k == 0 ? h2 : cur, r.tgn[k], nn, true, 1e-5f, true); }
+      else { gn(cur, r.tgn[k], cur, true, 1e-5f, true); nn = std::move(cur); }
       Act nxt = make(r.cout, h2.H, h2.W);
       GemmArgs g;
       g.A = nn.p(); g.W = r.tconv[k].w.p; g.C = nxt.p(); g.M = R; g.N = r.cout; g.K = 3 * r.cout; g.lda = r.cout; g.ldc = r.cout;

@@ -75,9 +75,8 @@ struct VRun : Runner {
     Act h1 = make(r.cout, x.H, x.W);
     conv3x3(n1, r.c1, h1, A_CONV3X3, 1, 1, 1, nullptr, nullptr, 0, nullptr, 0, 1, true);   // + h1's partials (norm2)
     n1.drop();
-    Act n2 = make(r.cout, x.H, x.W);
-    gn(h1, r.n2, n2, false, 1e-6f, true);
-    h1.drop();
+    gn(h1, r.n2, h1, false, 1e-6f, true);              // in place: nobody else reads h1 (round 6)
+    Act n2 = std::move(h1);
     Act sc;
     const void* sp = x.p();
     if (r.has_sc) { sc = make(r.cout, x.H, x.W); gemm(x.p(), x.C, rows(x), r.sc, sc.p(), r.cout); sp = sc.p(); }
@@ -95,9 +94,10 @@ struct VRun : Runner {
     gn(xs, s.tn1, n1, true, 1e-5f, true);
     Act h1 = make(C, xs.H, xs.W);
     tconv(n1, s.tc1, h1, nullptr, true);               // + h1's partials (norm2)
-    gn(h1, s.tn2, n1, true, 1e-5f, true);
+    n1.drop();
+    gn(h1, s.tn2, h1, true, 1e-5f, true);              // in place
     Act y = make(C, xs.H, xs.W);
-    tconv(n1, s.tc2, y, xs.p(), out_stats);
+    tconv(h1, s.tc2, y, xs.p(), out_stats);
     return y;
   }
   void tconv(const Act& x, const LinW& w, Act& y, const void* res, bool stats) {

@@ -13,7 +13,46 @@ from util import ROOT
 
 LIB = os.path.join(ROOT, "star_amd", "libstar_hip.so")
 READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+# the scheduled 256 x 320 tile (gemm.h, tile 19) with residual + GroupNorm-statistics epilogue: 508-512 registers; hipcc parks ONE
+# loop-invariant value in scratch before the K loop and reloads it behind it (round 6) -- allowed as long as the K loop itself is clean
+SPILL_OK = re.compile(r"gemm_kernelID\w+Li256ELi320ELi2ELi2ELi[013]ELi1ELb0ELb0ELi0ELi0ELi17ELi1E")
 MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
+
+
+def _code_objects():
+    """the gfx950 code objects bundled in the library, as temporary files"""
+    blob = open(LIB, "rb").read()
+    for m in re.finditer(re.escape(MAGIC), blob):
+        p = m.start()
+        n = struct.unpack_from("<Q", blob, p + 24)[0]
+        o = p + 32
+        for _ in range(n):
+            off, size, ts = struct.unpack_from("<QQQ", blob, o)
+            o += 24
+            triple = blob[o:o + ts].decode()
+            o += ts
+            if "gfx950" not in triple or size == 0:
+                continue
+            f = tempfile.NamedTemporaryFile(suffix=".co")
+            f.write(blob[p + off:p + off + size])
+            f.flush()
+            yield f
+
+
+def _disassembly():
+    """{kernel name: [instruction lines]} of every gfx950 kernel"""
+    out = {}
+    for f in _code_objects():
+        txt = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", f.name], capture_output=True, text=True, check=True).stdout
+        cur = None
+        for line in txt.split("\n"):
+            m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+            if m:
+                cur = out.setdefault(m.group(1), [])
+            elif cur is not None and line.startswith("\t"):
+                cur.append(line.strip().split("//")[0].strip())
+    return out
 
 
 def _kernels():
@@ -53,8 +92,48 @@ def kernels():
 
 
 def test_no_spills_no_scratch(kernels):
-    bad = {n: v for n, v in kernels.items() if v["spill"] or v["scratch"]}
+    bad = {n: v for n, v in kernels.items() if (v["spill"] or v["scratch"]) and not (SPILL_OK.search(n) and v["spill"] <= 1 and v["scratch"] <= 8)}
     assert not bad, f"kernels with register spills / scratch memory: {bad}"
+
+
+@pytest.fixture(scope="module")
+def disassembly():
+    if not (os.path.isfile(LIB) and os.path.isfile(OBJDUMP)):
+        pytest.skip("product library or llvm-objdump not available")
+    return _disassembly()
+
+
+def test_allowed_spill_stays_outside_the_k_loop(kernels, disassembly):
+    """the kernels SPILL_OK lets through touch scratch only before their first and behind their last MFMA"""
+    names = [n for n, v in kernels.items() if v["spill"] or v["scratch"]]
+    for n in names:
+        ins = disassembly[n]
+        mf = [i for i, l in enumerate(ins) if l.startswith("v_mfma")]
+        sc = [i for i, l in enumerate(ins) if l.startswith("scratch_")]
+        assert mf and sc and all(i < mf[0] or i > mf[-1] for i in sc), (n, sc, mf[0], mf[-1])
+
+
+def test_inline_asm_mfmas_have_no_valu_hazard(disassembly):
+    """MFMAs with their accumulator in architectural registers are inline asm (prim.h: mfma32_vform; gemm.h's 320-accumulator tile), invisible
+    to the compiler's hazard recognizer: no VALU instruction may write one of their operand registers within the four instructions in front
+    of them (round 6: hipcc re-materialised zero accumulators with v_mov right in front of the first MFMA, and on hardware the first
+    register arrived late -- gemm.h pins the zeros far from the loop)."""
+    n_asm = 0
+    for name, ins in disassembly.items():
+        if not re.search(r"gemm_kernelID\w+Li256ELi320ELi2ELi2E", name):   # (elsewhere VGPR-form MFMAs come from the builtin: the compiler sees them)
+            continue
+        for i, l in enumerate(ins):
+            m = re.match(r"v_mfma\S+ v\[(\d+):(\d+)\], v\[(\d+):(\d+)\], v\[(\d+):(\d+)\]", l)
+            if not m:
+                continue
+            n_asm += 1
+            rng = [(int(m.group(k)), int(m.group(k + 1))) for k in (1, 3, 5)]
+            for prev in ins[max(0, i - 4):i]:
+                w = re.match(r"(v_\S+)\s+v\[?(\d+)(?::(\d+))?\]?", prev)
+                if w and not w.group(1).startswith("v_mfma") and not w.group(1).startswith("v_cmp"):
+                    lo = int(w.group(2)); hi = int(w.group(3) or lo)
+                    assert not any(hi >= a and lo <= b for a, b in rng), (name, prev, l)
+    assert n_asm >= 400, n_asm   # 20 per K-tile body x the bodies of 18+ kernels
 
 
 def test_hot_kernels_keep_two_waves_per_simd(kernels):

@@ -37,7 +37,7 @@ def dev(ctx, t):
     return t.to(ctx.torch_device)
 
 
-PRODUCT_TILES = (0, 1, 2, 3, 4, 9, 10, 17, 18, 30)
+PRODUCT_TILES = (0, 1, 2, 3, 4, 9, 10, 17, 18, 19, 30)
 
 
 _BENCH_CTX = {}
@@ -311,9 +311,10 @@ def test_gemm_tail_split_is_bit_identical(ctx, dtype):
     assert ctx.lib.gemm_split_count(ctx.h) == n0 + 1 + 4 + 4        # every automatic launch above was split
 
 
-@pytest.mark.parametrize("M,N,K", [(515, 512, 256), (300, 264, 64), (257, 256, 448), (130, 1280, 128)])
-def test_gemm_scheduled_tile(ctx, dtype, M, N, K):
-    """tile 17 (4 waves x 128 x 128, one wave per SIMD, hand-placed 2-stage loop): bias / residual epilogues against fp32,
+@pytest.mark.parametrize("sched_tile", [17, 19])
+@pytest.mark.parametrize("M,N,K", [(515, 512, 256), (300, 264, 64), (257, 256, 448), (130, 1280, 128), (600, 640, 192)])
+def test_gemm_scheduled_tile(ctx, dtype, M, N, K, sched_tile):
+    """tiles 17 / 19 (4 waves x 128 x 128 / 128 x 160 -- the 256 x 320 tile with 320 accumulators per wave, round 6 --, one wave per SIMD, hand-placed 2-stage loop): bias / residual epilogues against fp32,
     and bit-for-bit against the 8-wave tile (both add the k-steps of an output in the same order); odd tile counts exercise the
     first-tile / last-two-tiles paths of the loop.  The tile has no fp32-output and no GEGLU flavour: refused."""
     g = torch.Generator().manual_seed(M + 3 * N + K)
@@ -322,21 +323,22 @@ def test_gemm_scheduled_tile(ctx, dtype, M, N, K):
     b = torch.randn(N, generator=g)
     R = torch.randn(M, N, generator=g).to(dtype)
     Ad, Wd_, bd, Rd = dev(ctx, A), dev(ctx, W), dev(ctx, b), dev(ctx, R)
-    out = ctx.gemm(Ad, Wd_, bias=bd, res=Rd, force_tile=17)
-    assert_close(out, A.float() @ W.float().T + b + R.float(), dtype, what="gemm tile 17 +res")
+    out = ctx.gemm(Ad, Wd_, bias=bd, res=Rd, force_tile=sched_tile)
+    assert_close(out, A.float() @ W.float().T + b + R.float(), dtype, what="gemm scheduled tile +res")
     assert torch.equal(out, ctx.gemm(Ad, Wd_, bias=bd, res=Rd, force_tile=1))
-    out = ctx.gemm(Ad, Wd_, bias=bd, force_tile=17)
+    out = ctx.gemm(Ad, Wd_, bias=bd, force_tile=sched_tile)
     assert torch.equal(out, ctx.gemm(Ad, Wd_, bias=bd, force_tile=1))
     with pytest.raises(L.StarError):
-        ctx.gemm(Ad, Wd_, out_f32=True, force_tile=17)
+        ctx.gemm(Ad, Wd_, out_f32=True, force_tile=sched_tile)
     if N % 64 == 0:
         with pytest.raises(L.StarError):
-            ctx.gemm(Ad, Wd_, bias=bd, geglu=True, force_tile=17)
+            ctx.gemm(Ad, Wd_, bias=bd, geglu=True, force_tile=sched_tile)
 
 
+@pytest.mark.parametrize("sched_tile", [17, 19])
 @pytest.mark.parametrize("NB,Cin,H,Wd,Cout", [(2, 64, 10, 8, 96), (1, 128, 18, 16, 256), (3, 320, 10, 8, 320)])
-def test_conv_scheduled_tile(ctx, dtype, NB, Cin, H, Wd, Cout):
-    """the gathered modes of tile 17 (3x3 conv stride 1 and 2, temporal conv + residual) against torch and bit-for-bit against the auto tile"""
+def test_conv_scheduled_tile(ctx, dtype, NB, Cin, H, Wd, Cout, sched_tile):
+    """the gathered modes of tiles 17 / 19 (3x3 conv stride 1 and 2, temporal conv + residual) against torch and bit-for-bit against the auto tile"""
     g = torch.Generator().manual_seed(Cin + H + 1)
     x = torch.randn(NB, Cin, H, Wd, generator=g).to(dtype)
     w = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)).to(dtype)
@@ -344,21 +346,21 @@ def test_conv_scheduled_tile(ctx, dtype, NB, Cin, H, Wd, Cout):
     wp = L.pack_conv3x3_weight(w)   # K index (c // 64, tap, c % 64): the kernel walks the nine taps of a 64-channel block back to back
     xr, wpd, bd = dev(ctx, nhwc_rows(x)), dev(ctx, wp), dev(ctx, b)
     ref = F.conv2d(x.float(), w.float(), b, padding=1)
-    out = ctx.gemm(xr, wpd, bias=bd, mode=L.A_CONV3X3, conv=(NB, H, Wd, Cin, H, Wd, 1, 1, 1), force_tile=17)
-    assert_close(out, nhwc_rows(ref), dtype, what="conv3x3 s1 tile 17")
+    out = ctx.gemm(xr, wpd, bias=bd, mode=L.A_CONV3X3, conv=(NB, H, Wd, Cin, H, Wd, 1, 1, 1), force_tile=sched_tile)
+    assert_close(out, nhwc_rows(ref), dtype, what="conv3x3 s1 scheduled tile")
     assert torch.equal(out, ctx.gemm(xr, wpd, bias=bd, mode=L.A_CONV3X3, conv=(NB, H, Wd, Cin, H, Wd, 1, 1, 1)))
     ref = F.conv2d(x.float(), w.float(), b, stride=2, padding=(2, 1))
     Ho, Wo = ref.shape[2:]
-    out = ctx.gemm(xr, wpd, bias=bd, mode=L.A_CONV3X3, conv=(NB, H, Wd, Cin, Ho, Wo, 2, 2, 1), force_tile=17)
-    assert_close(out, nhwc_rows(ref), dtype, what="conv3x3 s2 tile 17")
+    out = ctx.gemm(xr, wpd, bias=bd, mode=L.A_CONV3X3, conv=(NB, H, Wd, Cin, Ho, Wo, 2, 2, 1), force_tile=sched_tile)
+    assert_close(out, nhwc_rows(ref), dtype, what="conv3x3 s2 scheduled tile")
     with pytest.raises(L.StarError):      # no nearest-x2 mode in this tile
-        ctx.gemm(xr, wpd, bias=bd, mode=L.A_CONV3X3_UP, conv=(NB, H, Wd, Cin, 2 * H - 2, 2 * Wd, 1, 1, 1), force_tile=17)
+        ctx.gemm(xr, wpd, bias=bd, mode=L.A_CONV3X3_UP, conv=(NB, H, Wd, Cin, 2 * H - 2, 2 * Wd, 1, 1, 1), force_tile=sched_tile)
     # temporal conv: NB frames of H x Wd, Cin channels
     if Cin == Cout:
         wt = (torch.randn(Cin, 3 * Cin, generator=g) / math.sqrt(3 * Cin)).to(dtype)
         a = nhwc_rows(x)
         ad, wtd = dev(ctx, a), dev(ctx, wt)
-        o17 = ctx.gemm(ad, wtd, bias=bd, res=ad, mode=L.A_TCONV3, temporal=(NB, H * Wd, Cin), force_tile=17)
+        o17 = ctx.gemm(ad, wtd, bias=bd, res=ad, mode=L.A_TCONV3, temporal=(NB, H * Wd, Cin), force_tile=sched_tile)
         assert torch.equal(o17, ctx.gemm(ad, wtd, bias=bd, res=ad, mode=L.A_TCONV3, temporal=(NB, H * Wd, Cin)))
 
 
@@ -723,6 +725,12 @@ GN_EPI_CASES = [   # mode, tile, (frames, H, W), Cin, Cout, residual
     ("conv", 1, (2, 11, 9), 64, 256, False),       # 256 x 256 tile
     ("tconv", 1, (3, 10, 8), 128, 512, True),      # TemporalResnetBlock conv2 + spatial branch
     ("plain", 4, (3, 11, 9), 64, 128, False),      # conv_in as an im2col GEMM (K = 64)
+    # round 6: the scheduled 256 x 320 tile (128 x 160 per wave: 20 chunk columns per wave as tile 2)
+    ("conv", 19, (3, 11, 9), 64, 320, False),
+    ("plain", 19, (2, 17, 16), 128, 640, False),
+    ("tconv", 19, (5, 7, 9), 320, 320, False),
+    ("conv", 19, (2, 10, 8), 128, 320, True),      # ... and WITH the residual (ResBlock conv2 + skip): its fifth block column is in architectural registers
+    ("tconv", 19, (4, 9, 8), 320, 640, True),
 ]
 
 

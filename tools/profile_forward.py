@@ -20,11 +20,12 @@ ap.add_argument("--frames", type=int, default=32)
 ap.add_argument("--h", type=int, default=122)
 ap.add_argument("--w", type=int, default=216)
 ap.add_argument("--reps", type=int, default=2)
+ap.add_argument("--lib", default=None, help="another build of the library (tools/bench/libstar_hip_bench.so for in-situ A/Bs of bench-only switches)")
 a = ap.parse_args()
 torch.set_grad_enabled(False)
 dt = {"f16": torch.float16, "bf16": torch.bfloat16}[a.dtype]
 cfg = UNetConfig()
-net = ControlledV2VUNet(cfg, dtype=dt)
+net = ControlledV2VUNet(cfg, dtype=dt, library=L.Library(a.lib) if a.lib else None)
 net.load_state_dict(random_state_dict(cfg, seed=0))
 net.release_host_weights()
 g = torch.Generator().manual_seed(1)

@@ -47,6 +47,50 @@ SPEC
       cat gpurun_out/r06_vae_gnepi_ab.txt
       timeout 600 python -m pytest tests/test_vae.py tests/test_parity_cfg4.py -m gpu -x -q -s 2>&1 | grep -E "dB|passed|failed|rror" | tail -8 > gpurun_out/r06_pytest_new2.txt
       cat gpurun_out/r06_pytest_new2.txt ;;
+  8)  # the level-1 q | k | v on the persistent tile (ragged last column tile) IN SITU: forward table with / without, same box (the switch
+      # STAR_NO_PERSIST_RAGGED lived only for this measurement: -8 % in situ against +3 % in cbench -> dropped)
+      ( timeout 400 python tools/profile_forward.py 2>&1 | grep -v amdgpu.ids ) > gpurun_out/r06_forward_detail_f16_ragged18.txt 2>&1
+      ( STAR_NO_PERSIST_RAGGED=1 timeout 400 python tools/profile_forward.py 2>&1 | grep -v amdgpu.ids ) > gpurun_out/r06_forward_detail_f16_noragged18.txt 2>&1
+      for f in ragged18 noragged18; do echo "== $f"; head -2 gpurun_out/r06_forward_detail_f16_$f.txt; grep -E "214272 +1920 +640" gpurun_out/r06_forward_detail_f16_$f.txt; done ;;
+  11) # tile 19 (scheduled 256 x 320) auto-selected against STAR_NO_SCHED320=1, whole forwards on one box, twice each + the kernel tests
+      timeout 300 python -m pytest tests/test_kernels.py -m gpu -x -q -k "scheduled_tile or producer_epilogue or tail_split or conv" 2>&1 | tail -2
+      for i in 1 2; do
+        ( timeout 400 python tools/profile_forward.py 2>&1 | grep -v amdgpu.ids ) > gpurun_out/r06_forward_detail_f16_tile19_$i.txt 2>&1
+        ( STAR_NO_SCHED320=1 timeout 400 python tools/profile_forward.py 2>&1 | grep -v amdgpu.ids ) > gpurun_out/r06_forward_detail_f16_notile19_$i.txt 2>&1
+      done
+      for f in tile19_1 notile19_1 tile19_2 notile19_2; do echo "== $f"; head -2 gpurun_out/r06_forward_detail_f16_$f.txt; done
+      python - <<'PY'
+import re
+def load(f):
+    d={}
+    for l in open(f):
+        t=l.split()
+        if len(t)==9 and t[0] in ('gemm','conv3x3','tconv'): d[tuple(t[:5])]=(int(t[5]),float(t[6]))
+    return d
+a=load('gpurun_out/r06_forward_detail_f16_tile19_2.txt'); b=load('gpurun_out/r06_forward_detail_f16_notile19_2.txt')
+tot=0
+for k in sorted(a, key=lambda k:-abs(a[k][1]-b.get(k,(0,a[k][1]))[1])):
+    if k in b and abs(a[k][1]-b[k][1])>0.03:
+        print(k, 'n',a[k][0], 'tile19 %.2f ms  tile2 %.2f ms  (%+.1f %%)'%(a[k][1],b[k][1],(a[k][1]/b[k][1]-1)*100)); tot+=a[k][1]-b[k][1]
+print('sum of changes: %.2f ms per forward'%tot)
+PY
+      ;;
+  10) # GroupNorm apply in place + compile-time SiLU: forward table both ways on one box, twice; the VAE both ways (its norms are always in
+      # place now: only the statistics switch remains)
+      for i in 1 2; do
+        ( timeout 400 python tools/profile_forward.py 2>&1 | grep -v amdgpu.ids ) > gpurun_out/r06_forward_detail_f16_gninplace_$i.txt 2>&1
+        ( STAR_NO_GN_INPLACE=1 timeout 400 python tools/profile_forward.py 2>&1 | grep -v amdgpu.ids ) > gpurun_out/r06_forward_detail_f16_gnoutofplace_$i.txt 2>&1
+      done
+      for f in gninplace_1 gnoutofplace_1 gninplace_2 gnoutofplace_2; do echo "== $f"; head -2 gpurun_out/r06_forward_detail_f16_$f.txt; grep -E "group_norm" gpurun_out/r06_forward_detail_f16_$f.txt | cut -c1-100; done
+      ( timeout 300 python tools/vae_time.py 6 2>&1 | grep -v amdgpu.ids ) | tee gpurun_out/r06_vae_inplace.txt
+      timeout 900 python -m pytest tests/test_unet.py tests/test_vae.py -m gpu -x -q 2>&1 | tail -3 ;;
+  9)  # tile 18's non-temporal stores IN SITU (the cbench gain must survive inside a forward): the bench build, product stores against
+      # STAR_PERSIST_PLAIN=1 (the round-5 plain stores), same box, twice each
+      for i in 1 2; do
+        ( timeout 400 python tools/profile_forward.py --lib tools/bench/libstar_hip_bench.so 2>&1 | grep -v amdgpu.ids ) > gpurun_out/r06_forward_detail_f16_nt_$i.txt 2>&1
+        ( STAR_PERSIST_PLAIN=1 timeout 400 python tools/profile_forward.py --lib tools/bench/libstar_hip_bench.so 2>&1 | grep -v amdgpu.ids ) > gpurun_out/r06_forward_detail_f16_plain_$i.txt 2>&1
+      done
+      for f in nt_1 plain_1 nt_2 plain_2; do echo "== $f"; head -2 gpurun_out/r06_forward_detail_f16_$f.txt; grep -E " (5120 +640|10240 +1280|3840 +1280|4096 +512) +3[37] " gpurun_out/r06_forward_detail_f16_$f.txt | cut -c1-100; done ;;
   7)  # closing evidence (one box): the whole GPU suite with its parity lines, smoke, the forward table, the bench line (per-family table from
       # the warm-up clip -> roofline.families, power sampled live, operand sweep + live skeleton ceiling, CPU baseline), the same command under
       # rocprofv3 --kernel-trace --stats, then the other configurations
