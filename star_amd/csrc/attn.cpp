@@ -63,6 +63,12 @@ static int launch_flash(Ctx* ctx, const AttnArgs& a) {
     STAR_LAUNCH((flash_attn_v5_kernel<T, 0, 1, 0, 8>), dim3((unsigned)nblk8), dim3(512), (size_t)32768, ctx->stream, p);
     return 0;
   }
+  if (a.variant == 35) {   // round 6: the product kernel with the probabilities packed round-toward-zero (v_cvt_pkrtz_f16_f32), f16 / long key ranges
+    if constexpr (__is_same(T, f16)) {
+      if (a.Nk >= 1024) { STAR_LAUNCH((flash_attn_v5_kernel<T, 1, 1, 0, 4, 1>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p); return 0; }
+    }
+    return ctx->fail("flash_attn: variant 35 (round-toward-zero pack) is f16 with Nk >= 1024 only");
+  }
   if (a.variant == 32) { STAR_LAUNCH((flash_attn_v3_kernel<T, 2, 1, 0, 1>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p); return 0; }   // the product kernel of rounds 1-2
   if (a.variant == 30) { STAR_LAUNCH((flash_attn_v5_kernel<T, 0>), dim3((unsigned)nblk), dim3(256), (size_t)32768, ctx->stream, p); return 0; }
   if (a.variant == 31) {

@@ -636,6 +636,31 @@ STAR_DEV vec<T, 2> pk_add(vec<T, 2> a, vec<T, 2> b) {
   return a + b;
 #endif
 }
+// two fp32 -> packed f16, rounded TOWARD ZERO (v_cvt_pkrtz_f16_f32: one issue slot where the nearest-even v_cvt_pk_f16_f32 of gfx950
+// takes two; attn5.h RTZ).  The emulator truncates the nearest-even result back when it overshot; inf / NaN pass through; a finite value
+// beyond the f16 range truncates to the largest finite f16 like the instruction does.
+template <class T>
+STAR_DEV vec<T, 2> cvt_pkrtz(float a, float b) {
+  static_assert(__is_same(T, f16), "");
+#ifdef STAR_HOSTEMU
+  auto one = [](float v) -> f16 {
+    f16 r = (f16)v;
+    if (v != v) return r;
+    const float back = (float)r;
+    const bool finite_in = v - v == 0.f;
+    if (finite_in && (back - back != 0.f || __builtin_fabsf(back) > __builtin_fabsf(v))) {   // rounded away from zero (or to inf): one ulp back
+      uint16_t u = __builtin_bit_cast(uint16_t, r);
+      u = (uint16_t)(u - 1);
+      r = __builtin_bit_cast(f16, u);
+    }
+    return r;
+  };
+  vec<T, 2> r; r[0] = one(a); r[1] = one(b);
+  return r;
+#else
+  return __builtin_bit_cast(vec<T, 2>, __builtin_amdgcn_cvt_pkrtz(a, b));
+#endif
+}
 // max of the 8 values of a 16-byte chunk (f16: a tree of v_pk_max_f16)
 template <class T>
 STAR_DEV float max8(vec<T, 8> v) {

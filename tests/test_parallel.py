@@ -184,3 +184,76 @@ def test_replica_items_is_the_references_prompt_striding():
     assert list(replica_items([], rank=0, world=2)) == []
     with pytest.raises(ValueError):
         list(replica_items(lines, rank=3, world=3))
+
+
+def _worker_rccl(rank, world, port, q):
+    """the sharders on the REAL backend: `nccl` (= RCCL) with device tensors.  The GPU box has one GPU, so the world is 1: the
+    communicator is created, the metadata exchange and the payload all-gather run as RCCL collectives on cuda:0 (no host staging
+    branch is taken), and the results must equal the unsharded ones bit for bit."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        from star_amd.diffusion import GaussianDiffusion, noise_schedule
+        from star_amd.geometry import make_chunks
+        from star_amd.parallel import ChunkSharder, FrameSharder, gather_frames
+        res = {"backend_is_nccl": dist.get_backend() == "nccl"}
+        sig = noise_schedule(schedule="logsnr_cosine_interp", n=1000, zero_terminal_snr=True, scale_min=2.0, scale_max=4.0)
+        gd = GaussianDiffusion(sig)
+        g = torch.Generator().manual_seed(5)
+        A = (torch.randn(4, 4, generator=g) * 0.3).to(dev)
+
+        def model(x, t, y=None, hint=None, hint_chunk=None, variant_info=None):
+            h_ = hint_chunk if hint_chunk is not None else hint
+            return torch.einsum("oc,bcfhw->bofhw", A, x) * (1.0 + 0.1 * float(y.mean())) + 0.05 * h_ + 0.001 * float(t[0])
+
+        class Noise:
+            def __init__(self, x, a, b, seed=None):
+                self.g = torch.Generator().manual_seed(99)
+                self.shape, self.device = x.shape, x.device
+
+            def __call__(self, s, sn):
+                return torch.randn(self.shape, generator=self.g).to(self.device)
+
+        F_ = 72
+        noise = torch.randn(1, 4, F_, 10, 8, generator=g).to(dev)
+        hint = torch.randn(1, 4, F_, 10, 8, generator=g).to(dev)
+        y1, y2 = torch.randn(1, 77, 16, generator=g).to(dev), torch.randn(1, 77, 16, generator=g).to(dev)
+        for mx in (16, 32):
+            chunks = make_chunks(F_, 0, mx)
+            kw = dict(noise=noise, model=model, model_kwargs=[{"y": y1}, {"y": y2}, {"hint": hint}], guide_scale=7.5, guide_rescale=0.2,
+                      solver_mode="normal", steps=3, t_max=899, t_min=0, discretization="trailing", chunk_inds=chunks, noise_sampler_cls=Noise)
+            single = gd.sample_sr(**kw)
+            sharded = gd.sample_sr(chunk_executor=ChunkSharder(), **kw)
+            res[f"chunks{mx}"] = bool(sharded.is_cuda and torch.equal(single, sharded))
+        z = torch.arange(11 * 2 * 3, dtype=torch.float32, device=dev).reshape(11, 2, 3)
+        groups = [(i, min(i + 3, 11)) for i in range(0, 11, 3)]
+        out = FrameSharder().map_groups(groups, lambda a, b: z[a:b] * 2)
+        res["frames"] = bool(out.is_cuda and torch.equal(out, z * 2))
+        clip = torch.full((9, 8, 8, 3), 7, dtype=torch.uint8, device=dev)
+        allc = gather_frames(clip)
+        res["gather_u8"] = len(allc) == world and allc[0].is_cuda and bool(torch.equal(allc[0], clip))
+        # the bench's max-over-ranks reduction and barrier, as bench.py issues them
+        t = torch.tensor([1.25], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.barrier(device_ids=[0])
+        torch.cuda.synchronize()
+        res["allreduce_max"] = float(t) == 1.25
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sharders_on_rccl_device_tensors():
+    """RCCL on hardware: world size 1 is all a 1-GPU box offers -- communicator creation, the plan exchange and the
+    payload all-gathers run through the `nccl` backend on device tensors and reproduce the unsharded results bit for bit."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_rccl, args=(0, 1, _free_port(), q))
+    p.start()
+    rank, res = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert all(res.values()), res

@@ -37,6 +37,7 @@ template <int KIND> __device__ __forceinline__ void valu(float& x, f32x2& p, flo
   }
   else if constexpr (KIND == 8) { float s0 = spare[0]; asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(s0)); }
   else if constexpr (KIND == 9) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(p[0]));
+  else if constexpr (KIND == 11) asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "=v"(x) : "v"(y), "v"(z));   // round 6: the round-toward-zero pack (one pass?)
   else {   // KIND 10: the epilogue's read pattern -- v_fma_f32 whose operand is an element of ANOTHER (idle) 16-register accumulator block in VGPRs
     float s0 = spare[3];
     asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(x) : "v"(s0), "v"(y));
@@ -109,6 +110,13 @@ int main(int argc, char** argv) {
   const bool more = argc > 2 && atoi(argv[2]) != 0;    // second argument 1: the round-5 extension (more instruction kinds, two waves per SIMD)
   float* out;
   HCHECK(hipMalloc(&out, 256 * sizeof(float)));
+  if (argc > 2 && atoi(argv[2]) == 2) {   // round 6: the two f32 -> packed f16 converts side by side (one wave and two waves per SIMD)
+    sweep<0, 5>(out, iters, 1, "v_cvt_pk_f16_f32");
+    sweep<0, 11>(out, iters, 1, "v_cvt_pkrtz_f16_f32");
+    sweep<0, 5, 512>(out, iters, 1, "two waves per SIMD, v_cvt_pk_f16_f32");
+    sweep<0, 11, 512>(out, iters, 1, "two waves per SIMD, v_cvt_pkrtz_f16_f32");
+    return 0;
+  }
   if (!more) {
     for (int nb : {1, 256}) {
       sweep<0, 0>(out, iters, nb, "accumulators in AGPRs, VALU = v_fma_f32");

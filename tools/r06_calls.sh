@@ -6,6 +6,16 @@ mkdir -p gpurun_out
 R=${GRAFT_REPO_ROOT:-/root/repo}
 BL=$R/tools/bench/libstar_hip_bench.so
 case "${1:-1}" in
+  11) # the probabilities packed round-toward-zero (attn5.h RTZ, bench variant 35): (a) what the two converts cost beside an MFMA (probe),
+      # (b) the kernel A/B with socket power / clock beside it at the three self-attention lengths of cfg2, (c) accuracy of both against fp64
+      timeout 60 ./tools/probe/mfma_valu_overlap 20000 2 > gpurun_out/r06_probe_cvt_pkrtz.txt 2>&1; cat gpurun_out/r06_probe_cvt_pkrtz.txt
+      CBENCH_POWER=1 CBENCH_BATCH_MS=700 timeout 200 ./tools/cbench/cbench $BL f16 - 4 > gpurun_out/r06_attn_rtz_ab.txt 2>&1 <<'SPEC'
+attn 32 5 26352 26352 9,35,9,35
+attn 32 10 6696 6696 9,35,9,35
+attn 32 20 1728 1728 9,35
+SPEC
+      cat gpurun_out/r06_attn_rtz_ab.txt
+      ( timeout 300 python tools/attn_rtz_accuracy.py 9 35 2>&1 | grep -v amdgpu.ids ) | tee gpurun_out/r06_attn_rtz_accuracy.txt ;;
   1)  # (a) attention: one 512-thread workgroup per CU (variant 34) against the product kernel, with socket power / clock beside it;
       # (b) the traffic table: per (family, shape) >= 3 ms of a cfg2 forward, three single-group PMC passes on the torch-free harness
       CBENCH_POWER=1 CBENCH_BATCH_MS=700 timeout 120 ./tools/cbench/cbench $BL f16 - 4 > gpurun_out/r06_attn8_ab.txt 2>&1 <<'SPEC'
