@@ -6,6 +6,24 @@ mkdir -p gpurun_out
 R=${GRAFT_REPO_ROOT:-/root/repo}
 BL=$R/tools/bench/libstar_hip_bench.so
 case "${1:-1}" in
+  12) # the counter table again for the shapes whose kernel changed after call 1 (tile 19, composed FF GEMM): review r05 item 6
+      timeout 200 ./tools/cbench/cbench $BL f16 tools/cbench/r06_traffic_shapes_final.txt 6 > gpurun_out/r06_traffic_timing_final.txt 2>&1
+      cd /tmp && export TMPDIR=/tmp
+      P=$R/gpurun_out/r06_pmc_final; rm -rf $P; mkdir -p $P
+      i=0
+      grep -v '^#' $R/tools/cbench/r06_traffic_shapes_final.txt | grep -v '^\s*$' | while read -r line; do
+        echo "$line" > /tmp/one.txt
+        timeout 60 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $P/s${i}_FETCH -- $R/tools/cbench/cbench $BL f16 /tmp/one.txt 1 > $P/s${i}_FETCH.log 2>&1
+        timeout 60 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $P/s${i}_WRITE -- $R/tools/cbench/cbench $BL f16 /tmp/one.txt 1 > $P/s${i}_WRITE.log 2>&1
+        timeout 60 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE -d $P/s${i}_SQ -- $R/tools/cbench/cbench $BL f16 /tmp/one.txt 1 > $P/s${i}_SQ.log 2>&1
+        i=$((i+1))
+      done
+      cd $R
+      python tools/pmc_traffic_table.py tools/cbench/r06_traffic_shapes_final.txt gpurun_out/r06_pmc_final gpurun_out/r06_traffic_timing_final.txt > gpurun_out/r06_traffic_table_final.txt 2>&1
+      cat gpurun_out/r06_traffic_table_final.txt
+      find gpurun_out/r06_pmc_final -name "*.db" -size +2M -delete; du -sh gpurun_out/r06_pmc_final
+      # and the RCCL world-1 test of the sharders
+      timeout 600 python -m pytest tests/test_parallel.py -m gpu -x -q 2>&1 | tail -3 | tee gpurun_out/r06_pytest_rccl_world1.txt ;;
   11) # the probabilities packed round-toward-zero (attn5.h RTZ, bench variant 35): (a) what the two converts cost beside an MFMA (probe),
       # (b) the kernel A/B with socket power / clock beside it at the three self-attention lengths of cfg2, (c) accuracy of both against fp64
       timeout 60 ./tools/probe/mfma_valu_overlap 20000 2 > gpurun_out/r06_probe_cvt_pkrtz.txt 2>&1; cat gpurun_out/r06_probe_cvt_pkrtz.txt
