@@ -458,6 +458,32 @@ def test_flash_attention_self(ctx, dtype, B, heads, Nq, Nk, variant):
     assert_close(out, ref_attention(q, k, v, heads), dtype, what="flash self")
 
 
+def test_flash_attention_round_toward_zero_pack(ctx, dtype):
+    """bench variant 35 (attn5.h RTZ; round 6, measured and not adopted): the probabilities packed with v_cvt_pkrtz_f16_f32.  The row
+    sum is taken from the same rounded probabilities the PV MFMA multiplies, so the truncation's common shift cancels: the result
+    must sit within the product kernel's tolerance of the fp32 reference and close to the nearest-even kernel; it exists for f16 with
+    long key ranges only and says so otherwise.  (Exercises prim.h: cvt_pkrtz -- on the emulator its software statement, incl. the
+    underflow-to-zero and overflow-to-largest-finite cases the first draft got wrong.)"""
+    ctx = need_variant(ctx, False)
+    g = torch.Generator().manual_seed(35)
+    B, heads, Nq, Nk = 2, 2, 130, 1100
+    qkv = (torch.randn(B, Nk, 3 * heads * 64, generator=g) * 1.5).to(dtype)
+    C = heads * 64
+    qkvd = dev(ctx, qkv)
+    args = (qkvd[:, :Nq, :C], qkvd[:, :, C:2 * C], qkvd[:, :, 2 * C:], heads)
+    if dtype != torch.float16:
+        with pytest.raises(L.StarError):
+            ctx.attention(*args, variant=35)
+        return
+    out = ctx.attention(*args, variant=35)
+    ref = ref_attention(qkv[:, :Nq, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], heads)
+    assert_close(out, ref, dtype, what="flash, round-toward-zero pack")
+    rne = ctx.attention(*args, variant=9)
+    assert float((out.float() - rne.float()).abs().max()) <= 2.0 ** -9 * max(1.0, float(ref.abs().max()))
+    with pytest.raises(L.StarError):     # short key ranges keep fp32 row sums: no packed variant there
+        ctx.attention(qkvd[:, :Nq, :C], qkvd[:, :77, C:2 * C], qkvd[:, :77, 2 * C:], heads, variant=35)
+
+
 def test_flash_attention_cross_77(ctx, dtype):
     """cross-attention to the 77 text tokens, K/V shared by all frames (unet_v2v.py:476)."""
     g = torch.Generator().manual_seed(77)
