@@ -1,4 +1,5 @@
 // norm.cpp -- launchers for norm.h
+#include <cstdint>
 #include <cstdlib>
 #include "ops.h"
 #include "norm.h"
@@ -226,6 +227,12 @@ int op_gemv(Ctx* ctx, const float* x, const void* W, const float* b, float* y, i
 int op_softmax_rows(Ctx* ctx, const float* s, int lds, void* pout, int ldp, int rows, int n, float scale) {
   ProfScope ps(ctx, PK_MISC, 0.0, (double)rows * n * 10.0);
   SoftmaxParams p{s, pout, rows, n, lds, ldp, scale * 1.4426950408889634f};
+  // one-read form (norm.h: softmax_rows_vec_kernel) where the layout allows whole 8-element chunks: the VAE's logits (ld = Np, a multiple of 64)
+  if (!(lds & 3) && !(ldp & 7) && ldp >= 8 && n <= ldp && n <= lds && !((uintptr_t)s & 15) && !((uintptr_t)pout & 15)) {
+    if (ctx->dtype == DT_F16) STAR_LAUNCH((softmax_rows_vec_kernel<f16, 13>), dim3((unsigned)rows), dim3(256), (size_t)64, ctx->stream, p);
+    else STAR_LAUNCH((softmax_rows_vec_kernel<bf16, 13>), dim3((unsigned)rows), dim3(256), (size_t)64, ctx->stream, p);
+    return 0;
+  }
   if (ctx->dtype == DT_F16) STAR_LAUNCH((softmax_rows_kernel<f16>), dim3((unsigned)rows), dim3(256), (size_t)64, ctx->stream, p);
   else STAR_LAUNCH((softmax_rows_kernel<bf16>), dim3((unsigned)rows), dim3(256), (size_t)64, ctx->stream, p);
   return 0;

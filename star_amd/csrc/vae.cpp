@@ -110,8 +110,11 @@ struct VRun : Runner {
   }
   // Attention(heads = 1, dim_head = C = 512, residual_connection, GroupNorm eps 1e-6), per frame.  One head of width 512 does not
   // fit the d = 64 flash kernel (the output tile alone would be 512 accumulators per lane), so the logits go through HBM -- but
-  // only a bounded block of query rows at a time (<= 2 GiB of fp32 logits + 16-bit probabilities), so that the 133 712-token
-  // frames of the 2160p configuration need 2 GiB of scratch instead of 107 GB.  It is 0.3 % of a clip's time.
+  // only a bounded block of query rows at a time (<= 6 GiB of fp32 logits + 16-bit probabilities, every buffer below 4 GiB), so that
+  // the 133 712-token frames of the 2160p configuration need 6 GiB of scratch instead of 107 GB.  Round 6: the bound was 2 GiB, which
+  // cut a cfg2 frame (26 352 rows) into two blocks whose P V GEMM is 106 tiles of 256 x 256 on 256 CUs, and a 2160p frame into 2560-row
+  // blocks = 20 tiles; one block per cfg2 frame is 206 tiles, a 2160p block 7936 rows = 62.  If the pool cannot give 6 GiB the bound is
+  // halved down to the old one.  It is 0.5 % of a clip's time.
   Act attn(const AttnVW& a, Act x) {
     const int C = a.C, HW = x.H * x.W;
     const int Np = (HW + 63) & ~63;
@@ -120,12 +123,19 @@ struct VRun : Runner {
     Act q = make(C, x.H, x.W), k = make(C, x.H, x.W), o = make(C, x.H, x.W);
     gemm(n.p(), C, rows(x), a.q, q.p(), C);
     gemm(n.p(), C, rows(x), a.k, k.p(), C);
-    long long qc = ((long long)1 << 31) / ((long long)Np * (4 + (long long)es));   // query rows per block
-    if (const char* e = getenv("STAR_VAE_ATTN_ROWS")) qc = atoll(e);   // tests: force several query blocks on a small frame
-    qc = (qc / 256) * 256;
-    if (qc < 256) qc = 256;
-    if (qc > HW) qc = HW;
-    Buf vt(ctx, (size_t)C * Np * es), S(ctx, (size_t)qc * Np * 4), P(ctx, (size_t)qc * Np * es);
+    Buf vt(ctx, (size_t)C * Np * es), S, P;
+    long long qc = 0;
+    for (long long budget = (long long)6 << 30; budget >= ((long long)1 << 31); budget >>= 1) {
+      qc = budget / ((long long)Np * (4 + (long long)es));                  // query rows per block
+      if (const char* e = getenv("STAR_VAE_ATTN_ROWS")) qc = atoll(e);      // tests: force several query blocks on a small frame
+      qc = (qc / 256) * 256;
+      if (qc < 256) qc = 256;
+      if (qc > HW) qc = HW;
+      S = Buf(ctx, (size_t)qc * Np * 4);
+      P = Buf(ctx, (size_t)qc * Np * es);
+      if (S.p && P.p) break;
+      S.reset(); P.reset();
+    }
     if (!vt.p || !S.p || !P.p) { rc = ctx->fail("out of device memory (VAE attention)"); return x; }
     const float scale = 1.0f / sqrtf((float)C);
     for (int f = 0; f < F; ++f) {

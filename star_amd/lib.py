@@ -120,6 +120,7 @@ class Library:
         self.gemm_rowstats = _sig(c, "star_gemm_rowstats", i32, vp, ctypes.POINTER(GemmDesc), vp, i32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32))
         f32 = ctypes.c_float
         self.attn_fwd = _sig(c, "star_attn_fwd", i32, vp, ctypes.POINTER(AttnDesc))
+        self.softmax_rows = _sig(c, "star_softmax_rows", i32, vp, vp, i32, vp, i32, i32, i32, ctypes.c_float)
         self.temporal_attn_fwd = _sig(c, "star_temporal_attn_fwd", i32, vp, ctypes.POINTER(TAttnDesc))
         self.temporal_qkv_attn = _sig(c, "star_temporal_qkv_attn", i32, vp, ctypes.POINTER(TqDesc))
         self.group_norm = _sig(c, "star_group_norm", i32, vp, vp, i32, vp, i32, vp, vp, i32, i32, i32, f32, i32)
@@ -333,6 +334,18 @@ class Context:
         d.variant = variant
         d.causal = 1 if causal else 0
         self._check(self.lib.attn_fwd(self.h, ctypes.byref(d)), "attn_fwd")
+        return out
+
+    def softmax_rows(self, s, n, scale, ldp=None):
+        """P[r, :n] = softmax(s[r, :n] * scale) in the context dtype, P[r, n:ldp] = 0 (the VAE mid-block attention's logits pass, vae.cpp).
+        s: fp32 [rows, lds] (columns beyond n are ignored)."""
+        self._chk_tensor(s, torch.float32)
+        assert s.dim() == 2 and s.stride(1) == 1
+        rows = s.shape[0]
+        ldp = int(ldp if ldp is not None else s.shape[1])
+        out = torch.empty(rows, ldp, dtype=self.dtype, device=self.torch_device)
+        self._check(self.lib.softmax_rows(self.h, ctypes.c_void_p(s.data_ptr()), s.stride(0), ctypes.c_void_p(out.data_ptr()), ldp, rows, int(n), float(scale)),
+                    "softmax_rows")
         return out
 
     def temporal_attention(self, q, k, v, F_, HW, heads, out=None, scale=None):

@@ -484,6 +484,35 @@ def test_flash_attention_round_toward_zero_pack(ctx, dtype):
         ctx.attention(qkvd[:, :Nq, :C], qkvd[:, :77, C:2 * C], qkvd[:, :77, 2 * C:], heads, variant=35)
 
 
+@pytest.mark.parametrize("rows,n,lds,ldp", [
+    (5, 1000, 1024, 1024),        # one-read form, the row in registers, masked tail inside the last valid chunk
+    (3, 1024, 1024, 1024),        # no padding at all
+    (4, 70, 128, 128),            # fewer chunks than threads; padding chunks that are masked entirely
+    (2, 26352, 26368, 26368),     # the VAE's mid-block row at cfg2 (122 x 216 tokens)
+    (2, 30001, 30016, 30016),     # longer than 256 x 13 chunks: online maximum / sum, second read for the store
+    (3, 77, 77, 80),              # lds not a multiple of 4: the three-read kernel
+    (3, 100, 104, 100),           # ldp not a multiple of 8: the three-read kernel
+])
+def test_softmax_rows(ctx, dtype, rows, n, lds, ldp):
+    """the logits pass of the VAE's one-head d = 512 attention (diffusers Attention; vae.cpp: attn): P = softmax(S * scale) in the 16-bit
+    type with the padding columns written as zeros, by the one-read vector kernel where the layout allows and the scalar kernel elsewhere."""
+    g = torch.Generator().manual_seed(rows * 131 + n)
+    s = torch.randn(rows, lds, generator=g) * 30.0
+    s[0, min(n - 1, 17)] = 500.0            # a dominant logit
+    if rows > 1:
+        s[1, :n] = -40.0                    # a flat row
+    s[:, n:] = float("nan")                 # whatever lies beyond n must never be read into the result
+    scale = 1.0 / math.sqrt(512.0)
+    out = ctx.softmax_rows(dev(ctx, s), n, scale, ldp=ldp).float().cpu()
+    ref = torch.zeros(rows, ldp)
+    ref[:, :n] = torch.softmax(s[:, :n].double() * scale, dim=-1).float()
+    assert torch.isfinite(out).all()
+    assert float(out[:, n:].abs().max()) == 0.0 if ldp > n else True
+    eps = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
+    assert float((out - ref).abs().max()) <= 2.0 * eps * float(ref.max()), float((out - ref).abs().max())
+    assert float((out.sum(dim=1) - 1.0).abs().max()) <= 6e-3 if dtype == torch.float16 else 4e-2
+
+
 def test_flash_attention_cross_77(ctx, dtype):
     """cross-attention to the 77 text tokens, K/V shared by all frames (unet_v2v.py:476)."""
     g = torch.Generator().manual_seed(77)

@@ -6,6 +6,10 @@ mkdir -p gpurun_out
 R=${GRAFT_REPO_ROOT:-/root/repo}
 BL=$R/tools/bench/libstar_hip_bench.so
 case "${1:-1}" in
+  13) # the one-read softmax of the VAE's d = 512 attention: unit tests, the VAE tests, the per-shape table and the wall time again
+      timeout 900 python -m pytest tests/test_kernels.py tests/test_vae.py tests/test_fullsize.py -m gpu -x -q -k "softmax_rows or vae" 2>&1 | tail -3 | tee gpurun_out/r06_pytest_softmax_vec.txt
+      ( timeout 400 python tools/profile_vae.py 2>&1 | grep -v amdgpu.ids ) > gpurun_out/r06_vae_detail_softmax_vec.txt; grep -E "^==|algorithmic|misc" gpurun_out/r06_vae_detail_softmax_vec.txt
+      ( timeout 300 python tools/vae_time.py 6 2>&1 | grep -v amdgpu.ids ) | tee gpurun_out/r06_vae_time_softmax_vec.txt ;;
   12) # the counter table again for the shapes whose kernel changed after call 1 (tile 19, composed FF GEMM): review r05 item 6
       timeout 200 ./tools/cbench/cbench $BL f16 tools/cbench/r06_traffic_shapes_final.txt 6 > gpurun_out/r06_traffic_timing_final.txt 2>&1
       cd /tmp && export TMPDIR=/tmp
