@@ -96,15 +96,16 @@ def test_spatial_attention_cfg4_length_vs_fp32():
 @pytest.mark.gpu
 def test_vae_mid_attention_at_its_real_block_size(monkeypatch):
     """the single-head d = 512 mid-block attention of the VAE sends its fp32 logits through HBM in blocks of query rows bounded
-    by 2 GiB of scratch (vae.cpp).  Full-width encoder on one cfg2 frame (976 x 1728 -> 26352 tokens): the natural 2 GiB blocks
-    (2 of them) against the whole matrix at once -- bit-identical; on one cfg4 frame (2192 x 3904 -> 133712 tokens, 53 natural
-    blocks) against 5120-row blocks -- bit-identical and finite."""
+    by 6 GiB of scratch (vae.cpp; 2 GiB until round 6).  Full-width encoder on one cfg2 frame (976 x 1728 -> 26352 tokens): the
+    natural single block (one-read register softmax) against two 13568-row blocks -- bit-identical; on one cfg4 frame (2192 x 3904
+    -> 133712 tokens: 17 natural blocks of 7936 rows, a 4.25 GB logits buffer, rows too long for registers -> the online two-read
+    softmax) against 5120-row blocks -- bit-identical and finite."""
     from star_amd.vae import AutoencoderKLTemporalDecoder
     from star_amd.vae_topology import VaeConfig, random_vae_state_dict
     cfg = VaeConfig()
     vae = AutoencoderKLTemporalDecoder(cfg, dtype=torch.float16).load_state_dict(random_vae_state_dict(cfg, seed=2))
     g = torch.Generator().manual_seed(5)
-    for (H, W, other_rows) in ((976, 1728, 26368), (2192, 3904, 5120)):
+    for (H, W, other_rows) in ((976, 1728, 13568), (2192, 3904, 5120)):
         x = (torch.randn(1, 3, H // 8, W // 8, generator=g) * 0.5).clamp(-1, 1)
         x = torch.nn.functional.interpolate(x, size=(H, W), mode="bilinear").cuda()
         monkeypatch.delenv("STAR_VAE_ATTN_ROWS", raising=False)
