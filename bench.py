@@ -45,6 +45,21 @@ CONFIGS = {
 }
 
 
+def steps_detail(t0, ends, power):
+    """wall time of every timed step with the socket power / shader clock sampled during it: a clip is ~75 kJ at the socket cap, and
+    what a box sustains over many clips is not what its first one shows"""
+    out, a = [], t0
+    for b in ends:
+        d = {"ms": round((b - a) * 1e3, 1)}
+        ss = [x for x in (power.samples if power else []) if a <= x[0] < b]
+        if ss:
+            d["socket_W"] = round(sum(x[1] for x in ss) / len(ss), 1)
+            d["sclk_MHz"] = round(sum(x[2] for x in ss) / len(ss), 1)
+        out.append(d)
+        a = b
+    return out
+
+
 class PowerSampler:
     """socket power / shader clock of ONE GPU from sysfs hwmon, sampled on a host thread while kernels run (never rocm-smi beside a
     kernel on this pool: profiles/r03_attn7_ab.txt).  The hwmon directory is matched to the torch device through its PCI address."""
@@ -291,8 +306,11 @@ def main():
     uctx.profile_begin(kinds=["attn_self"])
     power = PowerSampler(local_rank, 0.1).start() if rank == 0 else None
     t0 = time.perf_counter()
+    step_ends = []
     for _ in range(args.steps):
         out = step()
+        torch.cuda.synchronize()            # per-step wall times (steps_detail): one host sync per ~minute-long clip
+        step_ends.append(time.perf_counter())
     barrier()
     elapsed = time.perf_counter() - t0
     if power:
@@ -421,6 +439,7 @@ def main():
                               "inside the timed region only the spatial self-attention launches are bracketed" if breakdown else
                               "no breakdown in this run (--warmup 0 without --breakdown on)",
             "setup_s": {"weights": round(t_weights, 1), "load": round(t_load, 1)},
+            "steps_detail": steps_detail(t0, step_ends, power),
             "algorithmic_pflop_per_step": (2 * evals * cfg["chunks"] * cfg["fwd_tflop"] + args.frames * VAE_TFLOP_PER_FRAME * cfg["vae_scale"]) / 1e3
                                           if not args.small and not custom else None,
             "timed_region_excludes": f"the final .cpu() of the fp32 output ({d2h_bytes / 1e6:.0f} MB, video_to_video_model.py:139): the frames are handed over "
