@@ -6,6 +6,14 @@ mkdir -p gpurun_out
 R=${GRAFT_REPO_ROOT:-/root/repo}
 BL=$R/tools/bench/libstar_hip_bench.so
 case "${1:-1}" in
+  14) # the round's switchable steps on / off on ONE box, whole clips (cfg2, the metric): composed FF GEMM, tile 19, GroupNorm in place
+      # (the VAE fixes and tile 18's non-temporal stores have no product switch and are in both)
+      for tag in on off on2; do
+        if [ $tag = off ]; then export STAR_NO_FFPO=1 STAR_NO_SCHED320=1 STAR_NO_GN_INPLACE=1; else unset STAR_NO_FFPO STAR_NO_SCHED320 STAR_NO_GN_INPLACE; fi
+        timeout 400 python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-operand-sweep > gpurun_out/r06_bench_same_box_$tag.json 2>> gpurun_out/r06_bench_same_box.err
+        python -c "
+import json; d=json.loads(open('gpurun_out/r06_bench_same_box_$tag.json').read().strip().splitlines()[-1]); print('$tag', round(d['value'],4), round(d['ms_per_step']), d['steps_detail'])"
+      done | tee gpurun_out/r06_same_box_round_steps.txt ;;
   13) # the one-read softmax of the VAE's d = 512 attention: unit tests, the VAE tests, the per-shape table and the wall time again
       timeout 900 python -m pytest tests/test_kernels.py tests/test_vae.py tests/test_fullsize.py -m gpu -x -q -k "softmax_rows or vae" 2>&1 | tail -3 | tee gpurun_out/r06_pytest_softmax_vec.txt
       ( timeout 400 python tools/profile_vae.py 2>&1 | grep -v amdgpu.ids ) > gpurun_out/r06_vae_detail_softmax_vec.txt; grep -E "^==|algorithmic|misc" gpurun_out/r06_vae_detail_softmax_vec.txt
