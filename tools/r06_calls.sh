@@ -6,6 +6,24 @@ mkdir -p gpurun_out
 R=${GRAFT_REPO_ROOT:-/root/repo}
 BL=$R/tools/bench/libstar_hip_bench.so
 case "${1:-1}" in
+  17) # call 14 again on another box, alternating, after one discarded clip (call 16's box drifted 1.4 % between its first and last baseline)
+      for tag in warm on1 off1 on2 off2 on3; do
+        ( case $tag in off*) export STAR_NO_FFPO=1 STAR_NO_SCHED320=1 STAR_NO_GN_INPLACE=1 ;; esac
+          timeout 400 python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-operand-sweep 2>> gpurun_out/r06_bench_same_box2.err | python -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); s=d['steps_detail'][0]; print('%-6s %8.1f ms  %6.1f W  %6.1f MHz  L0 attention %.0f TF/s' % ('$tag', s['ms'], s.get('socket_W',0), s.get('sclk_MHz',0), d['roofline']['achieved']))" )
+      done | tee gpurun_out/r06_same_box_round_steps2.txt ;;
+  16) # call 15's two surprises (the composed FF GEMM and tile 17 LOSE as whole clips) on a second box, alone and together
+      for sw in NONE STAR_NO_FFPO STAR_NO_SCHED BOTH NONE2; do
+        ( case $sw in NONE*) ;; BOTH) export STAR_NO_FFPO=1 STAR_NO_SCHED=1 ;; *) export $sw=1 ;; esac
+          timeout 400 python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-operand-sweep 2>> gpurun_out/r06_bench_switches2.err | python -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); s=d['steps_detail'][0]; print('%-18s %8.1f ms  %6.1f W  %6.1f MHz  L0 attention %.0f TF/s' % ('$sw', s['ms'], s.get('socket_W',0), s.get('sclk_MHz',0), d['roofline']['achieved']))" )
+      done | tee gpurun_out/r06_same_box_switches2.txt ;;
+  15) # every product A/B switch as a WHOLE CLIP on one box (the sustained regime decides, call 14): one clip per setting, baseline first and last
+      for sw in NONE STAR_NO_PERSIST STAR_NO_SCHED STAR_NO_ASTAT STAR_NO_TQ STAR_NO_SCHED320 STAR_NO_FFPO NONE2; do
+        ( case $sw in NONE*) ;; *) export $sw=1 ;; esac
+          timeout 400 python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-operand-sweep 2>> gpurun_out/r06_bench_switches.err | python -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); s=d['steps_detail'][0]; print('%-18s %8.1f ms  %6.1f W  %6.1f MHz  L0 attention %.0f TF/s' % ('$sw', s['ms'], s.get('socket_W',0), s.get('sclk_MHz',0), d['roofline']['achieved']))" )
+      done | tee gpurun_out/r06_same_box_switches.txt ;;
   14) # the round's switchable steps on / off on ONE box, whole clips (cfg2, the metric): composed FF GEMM, tile 19, GroupNorm in place
       # (the VAE fixes and tile 18's non-temporal stores have no product switch and are in both)
       for tag in on off on2; do
