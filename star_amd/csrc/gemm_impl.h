@@ -114,12 +114,15 @@ bool gemm_persist_covers(const GemmArgs& a);
 
 #ifdef STAR_BENCH_VARIANTS
 static bool no_sched320_env() { return std::getenv("STAR_NO_SCHED320") != nullptr; }
-static bool no_sched_env() { return std::getenv("STAR_NO_SCHED") != nullptr; }
+static bool no_sched_env() { return std::getenv("STAR_NO_SCHED") != nullptr || std::getenv("STAR_SCHED17") == nullptr; }
 static bool no_persist_env() { return std::getenv("STAR_NO_PERSIST") != nullptr; }
 #else
 static bool no_persist_env() { static const bool v = std::getenv("STAR_NO_PERSIST") != nullptr; return v; }   // read once (A/B switch)
 static bool no_sched320_env() { static const bool v = std::getenv("STAR_NO_SCHED320") != nullptr; return v; }   // read once (A/B switch)
-static bool no_sched_env() { static const bool v = std::getenv("STAR_NO_SCHED") != nullptr; return v; }   // read once (A/B switch)
+// tile 17 is OFF unless STAR_SCHED17=1 since the end of round 6: it wins 4-7 % per layer in kernel loops and single forwards and LOSES as whole
+// clips -- three alternations on one box 55.76 against 55.57 s without it (-0.34 %), -0.24 % and -0.2 % on two other boxes
+// (profiles/r06_same_box_tile17_clips.txt, r06_same_box_switches*.txt); the layers go to tile 19 (same arithmetic, bit-identical outputs)
+static bool no_sched_env() { static const bool v = std::getenv("STAR_NO_SCHED") != nullptr || std::getenv("STAR_SCHED17") == nullptr; return v; }   // read once (A/B switch)
 #endif
 
 template <class T>

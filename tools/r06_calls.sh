@@ -6,6 +6,12 @@ mkdir -p gpurun_out
 R=${GRAFT_REPO_ROOT:-/root/repo}
 BL=$R/tools/bench/libstar_hip_bench.so
 case "${1:-1}" in
+  19) # tile 17 alone, alternating whole clips after a discarded one (calls 15 / 16: -0.24 % / -0.2 % with it OFF)
+      for tag in warm on1 off1 on2 off2 on3 off3; do
+        ( case $tag in off*) export STAR_NO_SCHED=1 ;; esac
+          timeout 400 python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-operand-sweep 2>> gpurun_out/r06_bench_t17_clip.err | python -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); s=d['steps_detail'][0]; print('%-6s %8.1f ms  %6.1f W  %6.1f MHz  L0 attention %.0f TF/s' % ('$tag', s['ms'], s.get('socket_W',0), s.get('sclk_MHz',0), d['roofline']['achieved']))" )
+      done | tee gpurun_out/r06_same_box_tile17_clips.txt ;;
   18) # the composed FF GEMM alone, alternating whole clips after a discarded one (calls 15 / 16 disagree)
       for tag in warm on1 off1 on2 off2 on3 off3; do
         ( case $tag in off*) export STAR_NO_FFPO=1 ;; esac
